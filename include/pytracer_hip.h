@@ -1,0 +1,197 @@
+/* pytracer_hip.h — C ABI of the MI355X (gfx950) back end for pyTracer's
+ * ray–scene intersection and light-integration loop.
+ *
+ * The reference (zjiayao/pyTracer) is pure Python and has no FFI layer; its seams are
+ * duck-typed methods.  Each entry point below names the reference interface it replaces
+ * (file:line relative to the reference root).  Plain C types only: no torch, no C++.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pt_status otherwise; the message
+ *     is available from pt_last_error(ctx).  No exceptions cross the boundary.
+ *   - "host" pointers are read during the call and copied; "device" pointers must be
+ *     device memory on the context's GPU (e.g. torch tensor.data_ptr()) and stay owned
+ *     by the caller.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls on
+ *     one ctx are serialised by the caller; distinct ctxs are independent.
+ *   - all reals are IEEE binary64 ("f64"): the reference computes in numpy.float64
+ *     (pytracer/__init__.py:18) and hit/miss + primitive ids must match it bit-exactly.
+ */
+#ifndef PYTRACER_HIP_H
+#define PYTRACER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+typedef enum {
+    PT_OK = 0,
+    PT_ERR_ARG = -1,        /* bad argument (null pointer, size, unsupported enum) */
+    PT_ERR_HIP = -2,        /* a HIP runtime call failed */
+    PT_ERR_NO_SCENE = -3,   /* pt_intersect / pt_render before pt_scene_upload */
+    PT_ERR_DEPTH = -4,      /* BVH deeper than the 64-entry stack of bvh.py:332 */
+    PT_ERR_CAPACITY = -5    /* request exceeds a documented fixed capacity */
+} pt_status;
+
+/* ---- BSDF lobes: flattened result of Material.get_bsdf with ConstantTexture inputs
+ * (material/material.py:122-141 Matte, :166-189 Plastic, :208-222 Mirror, :280-299 Glass,
+ *  :329-364 Uber).  Lobes are stored in push_back order. ---------------------------- */
+typedef enum {
+    PT_LOBE_LAMBERT = 0,          /* reflection/bdf/bdf.py:310-338; R                       */
+    PT_LOBE_OREN_NAYAR = 1,       /* reflection/bdf/orennayar.py:36-62; R, a=A, b=B         */
+    PT_LOBE_MICROFACET_BLINN = 2, /* reflection/bdf/torrance.py:187-228 + Blinn :52-102 +
+                                     FresnelDielectric(a=eta_i, b=eta_t); c = exponent      */
+    PT_LOBE_SPEC_REFLECT = 3,     /* bdf.py:229-256; R; FresnelDielectric(a,b); c!=0 →
+                                     FresnelFullReflect (fresnel.py:75-83)                  */
+    PT_LOBE_SPEC_TRANSMIT = 4     /* bdf.py:259-307; R=T, a=ei, b=et                        */
+} pt_lobe_type;
+
+#define PT_MAX_LOBES 5
+
+typedef struct {
+    int32_t type;       /* pt_lobe_type */
+    int32_t _pad;
+    double R[3];        /* RGB scale (Spectrum = RGBSpectrum, spectral/spectrum.py:610) */
+    double a, b, c;
+} pt_lobe;
+
+typedef struct {
+    int32_t n_lobes;
+    int32_t _pad;
+    pt_lobe lobes[PT_MAX_LOBES];
+} pt_material;
+
+/* ---- lights (light/light.py) ------------------------------------------------------ */
+typedef enum {
+    PT_LIGHT_DIFFUSE_SPHERE = 0,  /* DiffuseAreaLight over one full Sphere (light.py:484-547,
+                                     shape/sphere.py:78-123,125-224)                        */
+    PT_LIGHT_SPOT = 1,            /* SpotLight (light.py:155-222)                           */
+    PT_LIGHT_POINT = 2            /* PointLight (light.py:118-152)                          */
+} pt_light_kind;
+
+typedef struct {
+    int32_t kind;       /* pt_light_kind */
+    int32_t ns;         /* Light.ns (light.py:38) */
+    int32_t ro;         /* sphere: Shape.ro (reverse orientation) */
+    int32_t _pad;
+    double emit[3];     /* DiffuseAreaLight.emit | SpotLight/PointLight.intensity */
+    double pos[3];      /* sphere: o2w(0,0,0) | spot/point: Light.pos */
+    double radius;      /* sphere radius */
+    double w2o[12];     /* rows 0..2 of the 4x4: sphere world→object | spot world→light */
+    double o2w[12];     /* rows 0..2 of the inverse */
+    double cos_width;   /* spot */
+    double cos_falloff; /* spot */
+} pt_light;
+
+/* ---- scene: linearised BVH (aggregate/accelerator/bvh.py:60-66,277-293) + triangles
+ * in BVH.primitives order (shape/triangle.py:426-435 world-space mesh.p) ------------- */
+typedef struct {
+    int32_t n_nodes, n_tris, n_materials, n_lights;
+    const double *node_bounds;   /* host [n_nodes][6]: pMin.xyz, pMax.xyz */
+    const int32_t *node_meta;    /* host [n_nodes][3]: offset, n_prim, axis */
+    const double *tri_verts;     /* host [n_tris][9]: p1,p2,p3 */
+    const int32_t *tri_mat;      /* host [n_tris]: material index */
+    const int32_t *tri_flip;     /* host [n_tris]: shape.ro ^ transform_swaps_handedness */
+    const pt_material *materials;/* host [n_materials] */
+    const pt_light *lights;      /* host [n_lights] */
+} pt_scene_desc;
+
+/* ---- camera (camera/projective.py:42-59,137-143,178-232) --------------------------- */
+typedef struct {
+    double r2c[16];     /* raster→camera, row-major 4x4 (ProjectiveCamera.r2c.m) */
+    double c2w[16];     /* camera→world (c2w.startTransform.m) */
+    double dx[3], dy[3];/* dxCam, dyCam */
+    double lens_rad, focal_dist;
+} pt_camera;
+
+/* ---- film (film/film.py:108-135) ---------------------------------------------------- */
+typedef struct {
+    int32_t x_res, y_res;
+    int32_t x_start, x_cnt, y_start, y_cnt;   /* xPixel_start/cnt, yPixel_start/cnt */
+    double xw, yw;                            /* filter half-widths */
+    double table[256];                        /* filter_table[16][16] (film.py:129-135) */
+} pt_film_desc;
+
+/* ---- sampler (sampler/sampler/stratified.py:34-89) ---------------------------------- */
+typedef struct {
+    int32_t x_start, x_end, y_start, y_end;   /* pixel window of the StratifiedSampler */
+    int32_t xs, ys;                           /* strata per pixel; spp = xs*ys */
+    int32_t jitter;
+    uint32_t seed;                            /* production stream only (table == NULL) */
+} pt_sampler_desc;
+
+typedef enum { PT_INTEG_DIRECT = 0, PT_INTEG_PATH = 1 } pt_integ_kind;
+
+/* integrator (integrator/surface/direct.py:36-105, path.py:27-144) */
+typedef struct {
+    int32_t kind;        /* pt_integ_kind */
+    int32_t max_depth;
+    int32_t pretest;     /* 1: trace the camera any-hit pre-test of renderer.py:168 as a
+                            separate ray (its result equals the closest-hit flag);
+                            0: skip it (identical image, fewer rays) */
+    int32_t _pad;
+} pt_integrator_desc;
+
+/* work shard: pixels [x0,x1)×[y0,y1) of the sampler window, sample indices [s0,s1) */
+typedef struct { int32_t x0, x1, y0, y1, s0, s1; } pt_tile;
+
+typedef struct {
+    uint64_t camera_samples;
+    uint64_t rays_closest;
+    uint64_t rays_any;
+    uint64_t node_visits;     /* slab tests executed (BVH._intersect_p calls) */
+    uint64_t tri_tests;       /* Triangle.intersect/_p calls */
+    uint64_t guard_nan, guard_neg, guard_inf;   /* renderer.py:185-193 */
+} pt_stats;
+
+typedef struct pt_ctx pt_ctx;
+
+/* library/ABI version */
+int pt_version(void);
+
+/* one context per GPU */
+int pt_ctx_create(int device, pt_ctx **out);
+int pt_ctx_destroy(pt_ctx *ctx);
+const char *pt_last_error(const pt_ctx *ctx);
+
+/* replaces: Scene(aggregate, lights, vr) holding a BVH (scene/scene.py:21-29) */
+int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene);
+
+/* replaces: Scene.intersect / Scene.intersect_p on a batch (scene/scene.py:35-39 →
+ * BVH.intersect bvh.py:322-365, BVH.intersect_p bvh.py:367-410, Triangle.intersect(_p)
+ * triangle.py:173-315).
+ *   rays   device f64 [8][n]: ox,oy,oz,dx,dy,dz,mint,maxt (component-major SoA)
+ *   any_hit=0: prim[n] = index into BVH.primitives or -1; t,b1,b2 [n] (t = ray.maxt after)
+ *   any_hit=1: prim[n] = 1 if occluded else 0; t,b1,b2 may be NULL
+ *   stats  host, may be NULL: node_visits / tri_tests / rays_* are ADDED to it */
+int pt_intersect(pt_ctx *ctx, const double *rays, int64_t n, int any_hit,
+                 int32_t *prim, double *t, double *b1, double *b2,
+                 pt_stats *stats, void *stream);
+
+/* replaces: the body of SamplerRendererTask.__call__ (renderer/renderer.py:132-198):
+ * sample generation → camera ray → SamplerRenderer.li → guards → ImageFilm.add_sample.
+ *   sample_table  device f64 [n_window_samples][dims] or NULL.  Non-NULL = parity mode:
+ *                 row r holds (imageX,imageY,lens_u,lens_v,time, oneD..., twoD...) of the
+ *                 r-th sample in reference order (y, x, s) over the sampler window, and
+ *                 rng() draws are the counter hash u(r,k) documented in DESIGN.md.
+ *   film_accum    device f64 [y_cnt][x_cnt][4] = Lxyz[3], weight_sum; ADDED to.
+ *   sample_L      device f64 [n_tile_samples][3] or NULL: per-sample radiance after guards.
+ *   stats         host, may be NULL: counters are ADDED. */
+int pt_render(pt_ctx *ctx, const pt_camera *cam, const pt_film_desc *film,
+              const pt_sampler_desc *sampler, const pt_integrator_desc *integ,
+              const pt_tile *tile, const double *sample_table, int32_t table_dims,
+              double *film_accum, double *sample_L, pt_stats *stats, void *stream);
+
+/* replaces: the pixel loop of ImageFilm.write_image (film/film.py:237-256):
+ * rgb[y][x] = max(0, xyz2rgb(Lxyz)/weight_sum).  film_accum device [y][x][4] → rgb device
+ * [y][x][3]. */
+int pt_film_resolve(pt_ctx *ctx, const double *film_accum, int32_t x_cnt, int32_t y_cnt,
+                    double *rgb, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYTRACER_HIP_H */

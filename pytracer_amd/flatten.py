@@ -1,0 +1,419 @@
+"""Host-side flattening of a pyTracer-shaped object graph into the arrays the C ABI takes.
+
+Only PUBLIC attributes of the reference classes are read:
+``scene.aggregate.{nodes,primitives}``, ``prim.shape.{mesh,v,ro,transform_swaps_handedness}``,
+``prim.material``, ``scene.lights``, ``camera.{r2c,c2w,dxCam,dyCam,lens_rad,focal_dist,film}``,
+``film.*``, ``sampler.*``.  The same structure can be loaded from the ``tests/golden`` fixture
+format (``flat_scene_from_npz``), which is how the GPU box — where the reference does not
+exist — gets its scenes.
+
+Materials are evaluated at flatten time (every supported texture is a ConstantTexture) into
+the ordered lobe list ``Material.get_bsdf`` would push
+(reference pytracer/material/material.py:122-141, 166-189, 208-222, 280-299, 329-364).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+
+EPS = 1e-5   # pytracer/__init__.py
+
+
+# --------------------------------------------------------------------------------------
+# materials → lobes
+# --------------------------------------------------------------------------------------
+def _clip(v):
+    """util.clip / Spectrum.clip: clip to [0, inf) (utility/utility.py:110-116)."""
+    return np.clip(np.asarray(v, np.float64), 0., np.inf)
+
+
+def _spec(v):
+    v = np.asarray(v, np.float64)
+    return np.full(3, float(v)) if v.ndim == 0 else v.astype(np.float64).copy()
+
+
+def _is_black(s):
+    """CoefficientSpectrum.is_black (spectral/spectrum.py:182-187)."""
+    return bool((np.asarray(s) < EPS).all())
+
+
+def _blinn_exponent(rough):
+    """Blinn.__init__ clips the exponent at 10000 (reflection/bdf/torrance.py:66-67)."""
+    return float(np.clip(1. / rough, -np.inf, 10000.))
+
+
+def lobes_from_params(kind, **p):
+    """Ordered lobe list [(type, R[3], a, b, c)] for one material record.
+
+    kind: 'matte' | 'uber' | 'plastic' | 'mirror' | 'glass'
+    """
+    out = []
+    if kind == 'matte':                         # material.py:122-141
+        r = _clip(_spec(p['Kd']))
+        sigma = float(np.clip(p['sigma'], 0., 90.))
+        if sigma == 0.:
+            out.append((A.PT_LOBE_LAMBERT, r, 0., 0., 0.))
+        else:                                   # OrenNayar.__init__, orennayar.py:36-42
+            sig = np.deg2rad(sigma)
+            sig_sq = sig * sig
+            a = 1. - (sig_sq / (2. * (sig_sq + 0.33)))
+            b = .45 * sig_sq / (sig_sq + .09)
+            out.append((A.PT_LOBE_OREN_NAYAR, r, float(a), float(b), 0.))
+    elif kind == 'uber':                        # material.py:329-364
+        op = _clip(_spec(p['opacity']))
+        if not np.array_equal(op, [1., 1., 1.]):
+            out.append((A.PT_LOBE_SPEC_TRANSMIT, 1. - op, 1., 1., 0.))
+        kd = op * _clip(_spec(p['Kd']))
+        if not _is_black(kd):
+            out.append((A.PT_LOBE_LAMBERT, kd, 0., 0., 0.))
+        e = float(p['eta'])
+        ks = op * _clip(_spec(p['Ks']))
+        if not _is_black(ks):
+            out.append((A.PT_LOBE_MICROFACET_BLINN, ks, e, 1., _blinn_exponent(float(p['roughness']))))
+        kr = op * _clip(_spec(p['Kr']))
+        if not _is_black(kr):
+            out.append((A.PT_LOBE_SPEC_REFLECT, kr, e, 1., 0.))
+        kt = op * _clip(_spec(p['Kt']))
+        if not _is_black(kt):
+            out.append((A.PT_LOBE_SPEC_TRANSMIT, kt, e, 1., 0.))
+    elif kind == 'plastic':                     # material.py:166-189
+        out.append((A.PT_LOBE_LAMBERT, _clip(_spec(p['Kd'])), 0., 0., 0.))
+        out.append((A.PT_LOBE_MICROFACET_BLINN, _clip(_spec(p['Ks'])), 1.5, 1.,
+                    _blinn_exponent(float(p['roughness']))))
+    elif kind == 'mirror':                      # material.py:208-222
+        r = _clip(_spec(p['Kr']))
+        if not _is_black(r):
+            out.append((A.PT_LOBE_SPEC_REFLECT, r, 1., 1., 1.))      # c != 0: FresnelFullReflect
+    elif kind == 'glass':                       # material.py:280-299
+        ior = float(p['index'])
+        r = _clip(_spec(p['Kr']))
+        if not _is_black(r):
+            out.append((A.PT_LOBE_SPEC_REFLECT, r, 1., ior, 0.))
+        t = _clip(_spec(p['Kt']))
+        if not _is_black(t):
+            out.append((A.PT_LOBE_SPEC_TRANSMIT, t, 1., ior, 0.))
+    else:
+        raise NotImplementedError('material kind %r is outside the supported hot path' % (kind,))
+    if len(out) > A.PT_MAX_LOBES:
+        raise ValueError('more than %d lobes' % A.PT_MAX_LOBES)
+    return out
+
+
+def _tex(t):
+    """Evaluate a ConstantTexture (texture/texture/__init__.py:41-46)."""
+    if type(t).__name__ != 'ConstantTexture':
+        raise NotImplementedError('only ConstantTexture is on the supported hot path, got %s' % type(t).__name__)
+    return t.value
+
+
+def material_params(mat):
+    """(kind, params) of a reference Material instance, read by attribute."""
+    nm = type(mat).__name__
+    if getattr(mat, 'bump_map', None) is not None:
+        raise NotImplementedError('bump mapping is outside the supported hot path')
+    if nm == 'MatteMaterial':
+        return 'matte', dict(Kd=_tex(mat.Kd), sigma=_tex(mat.sigma))
+    if nm == 'UberMaterial':
+        return 'uber', dict(Kd=_tex(mat.Kd), Ks=_tex(mat.Ks), Kr=_tex(mat.Kr), Kt=_tex(mat.Kt),
+                            roughness=_tex(mat.roughness), opacity=_tex(mat.opacity), eta=_tex(mat.eta))
+    if nm == 'PlasticMaterial':
+        return 'plastic', dict(Kd=_tex(mat.Kd), Ks=_tex(mat.Ks), roughness=_tex(mat.roughness))
+    if nm == 'MirrorMaterial':
+        return 'mirror', dict(Kr=_tex(mat.Kr))
+    if nm == 'GlassMaterial':
+        return 'glass', dict(Kr=_tex(mat.Kr), Kt=_tex(mat.Kt), index=_tex(mat.index))
+    raise NotImplementedError('material %s is outside the supported hot path' % nm)
+
+
+def _pack_material(lobes):
+    m = A.pt_material()
+    m.n_lobes = len(lobes)
+    for i, (tp, R, a, b, c) in enumerate(lobes):
+        m.lobes[i].type = tp
+        m.lobes[i].R[:] = [float(x) for x in R]
+        m.lobes[i].a, m.lobes[i].b, m.lobes[i].c = float(a), float(b), float(c)
+    return m
+
+
+# --------------------------------------------------------------------------------------
+# lights
+# --------------------------------------------------------------------------------------
+def _rows12(m):
+    return [float(x) for x in np.asarray(m, np.float64)[:3, :].ravel()]
+
+
+def _pack_light(rec):
+    lt = A.pt_light()
+    kind = rec['kind']
+    lt.kind = kind
+    lt.ns = max(1, int(rec.get('ns', 1)))
+    eye = np.eye(4)
+    lt.w2o[:] = _rows12(eye)
+    lt.o2w[:] = _rows12(eye)
+    if kind == A.PT_LIGHT_DIFFUSE_SPHERE:
+        r = float(rec['radius'])
+        full = (abs(rec['zmin'] + r) == 0. and abs(rec['zmax'] - r) == 0. and
+                abs(rec['phimax'] - 2. * np.pi) < 1e-15)
+        if not full:
+            raise NotImplementedError('partial spheres are outside the supported hot path')
+        lt.ro = int(rec.get('ro', 0))
+        lt.emit[:] = [float(x) for x in _spec(rec['emit'])]
+        o2w = np.asarray(rec['o2w'], np.float64)
+        lt.pos[:] = [float(o2w[i, 3]) for i in range(3)]      # o2w(Point(0,0,0)); affine
+        lt.radius = r
+        lt.w2o[:] = _rows12(rec['w2o'])
+        lt.o2w[:] = _rows12(o2w)
+    elif kind == A.PT_LIGHT_SPOT:
+        lt.emit[:] = [float(x) for x in _spec(rec['intensity'])]
+        lt.pos[:] = [float(x) for x in rec['pos']]
+        lt.w2o[:] = _rows12(rec['w2l'])
+        lt.cos_width = float(rec['cos_width'])
+        lt.cos_falloff = float(rec['cos_falloff'])
+    elif kind == A.PT_LIGHT_POINT:
+        lt.emit[:] = [float(x) for x in _spec(rec['intensity'])]
+        lt.pos[:] = [float(x) for x in rec['pos']]
+    else:
+        raise NotImplementedError('light kind %r' % (kind,))
+    return lt
+
+
+def light_record(light):
+    """Plain-dict record of a reference Light instance, read by attribute."""
+    nm = type(light).__name__
+    if nm == 'DiffuseAreaLight':
+        shapes = light.shape_set.shapes
+        if len(shapes) != 1 or type(shapes[0]).__name__ != 'Sphere':
+            raise NotImplementedError('DiffuseAreaLight over anything but one Sphere is outside the supported hot path')
+        sp = shapes[0]
+        return dict(kind=A.PT_LIGHT_DIFFUSE_SPHERE, emit=np.array(light.emit), ns=light.ns, radius=sp.radius,
+                    o2w=np.array(sp.o2w.m), w2o=np.array(sp.w2o.m), ro=bool(sp.ro), zmin=sp.zmin, zmax=sp.zmax,
+                    phimax=sp.phiMax)
+    if nm == 'SpotLight':
+        return dict(kind=A.PT_LIGHT_SPOT, pos=np.array(light.pos), intensity=np.array(light.intensity), ns=light.ns,
+                    w2l=np.array(light.w2l.m), cos_width=light.cos_width, cos_falloff=light.cos_falloff)
+    if nm == 'PointLight':
+        return dict(kind=A.PT_LIGHT_POINT, pos=np.array(light.pos), intensity=np.array(light.intensity), ns=light.ns)
+    raise NotImplementedError('light %s is outside the supported hot path' % nm)
+
+
+# --------------------------------------------------------------------------------------
+# the flat scene
+# --------------------------------------------------------------------------------------
+class FlatScene(object):
+    """Arrays of one scene in the layout pt_scene_desc points at (all host memory)."""
+
+    def __init__(self, node_bounds, node_meta, tri_verts, tri_mat, tri_flip, material_lobes, light_records):
+        self.node_bounds = np.ascontiguousarray(node_bounds, np.float64).reshape(-1, 6)
+        self.node_meta = np.ascontiguousarray(node_meta, np.int32).reshape(-1, 3)
+        self.tri_verts = np.ascontiguousarray(tri_verts, np.float64).reshape(-1, 9)
+        self.tri_mat = np.ascontiguousarray(tri_mat, np.int32).ravel()
+        self.tri_flip = np.ascontiguousarray(tri_flip, np.int32).ravel()
+        self.material_lobes = list(material_lobes)
+        self.light_records = list(light_records)
+        n, p = len(self.node_bounds), len(self.tri_verts)
+        if len(self.node_meta) != n or len(self.tri_mat) != p or len(self.tri_flip) != p:
+            raise ValueError('inconsistent scene array lengths')
+        if p and (self.tri_mat.min() < 0 or self.tri_mat.max() >= max(1, len(self.material_lobes))):
+            raise ValueError('material index out of range')
+        self._check_tree()
+        self._materials = (A.pt_material * max(1, len(self.material_lobes)))(
+            *[_pack_material(l) for l in self.material_lobes])
+        self._lights = (A.pt_light * max(1, len(self.light_records)))(*[_pack_light(r) for r in self.light_records])
+
+    def _check_tree(self):
+        """Every index the kernels will dereference is validated here, on the host."""
+        n, p = len(self.node_bounds), len(self.tri_verts)
+        m = self.node_meta
+        if n == 0:
+            return
+        leaf = m[:, 1] > 0
+        if (m[:, 1] < 0).any():
+            raise ValueError('negative n_prim')
+        lo = m[leaf, 0]
+        if len(lo) and (lo.min() < 0 or (lo + m[leaf, 1]).max() > p):
+            raise ValueError('leaf primitive range out of bounds')
+        inner = ~leaf
+        idx = np.nonzero(inner)[0]
+        if len(idx):
+            if (m[inner, 0] <= idx).any() or (m[inner, 0] >= n).any() or (idx + 1 >= n).any():
+                raise ValueError('interior child index out of bounds')
+            if (m[inner, 2] < 0).any() or (m[inner, 2] > 2).any():
+                raise ValueError('split axis out of range')
+
+    @property
+    def n_nodes(self):
+        return len(self.node_bounds)
+
+    @property
+    def n_tris(self):
+        return len(self.tri_verts)
+
+    @property
+    def n_lights(self):
+        return len(self.light_records)
+
+    def light_ns(self):
+        return [max(1, int(r.get('ns', 1))) for r in self.light_records]
+
+    def desc(self):
+        d = A.pt_scene_desc()
+        d.n_nodes, d.n_tris = self.n_nodes, self.n_tris
+        d.n_materials, d.n_lights = len(self.material_lobes), len(self.light_records)
+        d.node_bounds = self.node_bounds.ctypes.data
+        d.node_meta = self.node_meta.ctypes.data
+        d.tri_verts = self.tri_verts.ctypes.data
+        d.tri_mat = self.tri_mat.ctypes.data
+        d.tri_flip = self.tri_flip.ctypes.data
+        d.materials = C.cast(self._materials, C.POINTER(A.pt_material))
+        d.lights = C.cast(self._lights, C.POINTER(A.pt_light))
+        return d
+
+    def table_dims(self, integ_kind):
+        """Length of one sample-table row (sampler/sample.py:36-76 with the requests of
+        direct.py:46-62 or path.py:34-42)."""
+        if integ_kind == A.PT_INTEG_PATH:
+            return 35
+        return 5 + 6 * sum(self.light_ns())
+
+
+def flatten_scene(scene):
+    """FlatScene from a reference-shaped ``Scene`` whose aggregate is a ``BVH`` of triangles."""
+    agg = scene.aggregate
+    nodes = agg.nodes or []
+    prims = agg.primitives
+    nb = np.empty((len(nodes), 6), np.float64)
+    nm = np.empty((len(nodes), 3), np.int32)
+    for i, nd in enumerate(nodes):
+        nb[i, 0:3] = nd.bounds.pMin
+        nb[i, 3:6] = nd.bounds.pMax
+        nm[i] = (nd.offset, nd.n_prim, nd.axis)
+    tv = np.empty((len(prims), 9), np.float64)
+    tm = np.empty(len(prims), np.int32)
+    tf = np.empty(len(prims), np.int32)
+    mats, lobes = [], []
+    for i, pr in enumerate(prims):
+        sh = pr.shape
+        if type(sh).__name__ != 'Triangle':
+            raise NotImplementedError('only triangles may be in the BVH (got %s)' % type(sh).__name__)
+        m = sh.mesh
+        if m.uvs is not None or m.n is not None or m.s is not None or m.alphaTexture is not None:
+            raise NotImplementedError('meshes with uv / N / S / alpha are outside the supported hot path')
+        if getattr(pr, 'areaLight', None) is not None:
+            raise NotImplementedError('emissive primitives are outside the supported hot path')
+        for k in range(3):
+            tv[i, 3 * k:3 * k + 3] = m.p[m.vertexIndex[sh.v + k]]
+        tf[i] = int(bool(sh.ro) ^ bool(sh.transform_swaps_handedness))
+        mid = next((j for j, mm in enumerate(mats) if mm is pr.material), None)
+        if mid is None:
+            mats.append(pr.material)
+            kind, params = material_params(pr.material)
+            lobes.append(lobes_from_params(kind, **params))
+            mid = len(mats) - 1
+        tm[i] = mid
+    return FlatScene(nb, nm, tv, tm, tf, lobes, [light_record(l) for l in scene.lights])
+
+
+_MAT_KINDS = {0: 'matte', 1: 'uber', 2: 'plastic', 3: 'mirror', 4: 'glass'}
+
+
+def flat_scene_from_npz(d):
+    """FlatScene from the fixture format written by tools/oracle/gen_fixtures.py:dump_scene."""
+    lobes = []
+    for i in range(int(d['n_materials'])):
+        pre = 'mat%d_' % i
+        params = {k[len(pre):]: d[k] for k in d.keys() if k.startswith(pre) and k != pre + 'kind'}
+        lobes.append(lobes_from_params(_MAT_KINDS[int(d[pre + 'kind'])], **params))
+    lights = []
+    for i in range(int(d['n_lights'])):
+        pre = 'light%d_' % i
+        lights.append({k[len(pre):]: (d[k].item() if d[k].ndim == 0 else d[k]) for k in d.keys() if k.startswith(pre)})
+    return FlatScene(d['node_bounds'], d['node_meta'], d['tri_verts'], d['tri_mat'], d['tri_flip'], lobes, lights)
+
+
+# --------------------------------------------------------------------------------------
+# camera / film / sampler / integrator descriptors
+# --------------------------------------------------------------------------------------
+def camera_desc(r2c, c2w, dx, dy, lens_rad=0., focal_dist=0.):
+    c = A.pt_camera()
+    c.r2c[:] = [float(x) for x in np.asarray(r2c, np.float64).ravel()]
+    c.c2w[:] = [float(x) for x in np.asarray(c2w, np.float64).ravel()]
+    c.dx[:] = [float(x) for x in dx]
+    c.dy[:] = [float(x) for x in dy]
+    c.lens_rad, c.focal_dist = float(lens_rad), float(focal_dist)
+    return c
+
+
+def camera_desc_from_object(camera):
+    if type(camera).__name__ != 'PerspectiveCamera':
+        raise NotImplementedError('only PerspectiveCamera is on the supported hot path')
+    c2w = camera.c2w
+    if getattr(c2w, 'animated', False):
+        raise NotImplementedError('animated camera transforms are outside the supported hot path')
+    return camera_desc(camera.r2c.m, c2w.startTransform.m, camera.dxCam, camera.dyCam,
+                       camera.lens_rad, camera.focal_dist)
+
+
+def film_desc(x_res, y_res, win, xw, yw, table):
+    f = A.pt_film_desc()
+    f.x_res, f.y_res = int(x_res), int(y_res)
+    f.x_start, f.x_cnt, f.y_start, f.y_cnt = [int(v) for v in win]
+    f.xw, f.yw = float(xw), float(yw)
+    t = np.asarray(table, np.float64)
+    if t.shape != (16, 16):
+        raise ValueError('filter table must be 16x16 (FILTER_TABLE_SIZE, pytracer/__init__.py)')
+    f.table[:] = [float(x) for x in t.ravel()]
+    return f
+
+
+def film_desc_from_object(film):
+    return film_desc(film.xResolution, film.yResolution,
+                     (film.xPixel_start, film.xPixel_cnt, film.yPixel_start, film.yPixel_cnt),
+                     film.filter.xw, film.filter.yw, film.filter_table)
+
+
+def camera_film_from_npz(d):
+    cam = camera_desc(d['cam_r2c'], d['cam_c2w'], d['cam_dx'], d['cam_dy'], float(d['cam_lens_rad']),
+                      float(d['cam_focal']))
+    film = film_desc(d['film_res'][0], d['film_res'][1], d['film_win'], d['filt_w'][0], d['filt_w'][1],
+                     d['filt_table'])
+    return cam, film
+
+
+def sampler_desc(x_start, x_end, y_start, y_end, xs, ys, jitter=True, seed=0):
+    s = A.pt_sampler_desc()
+    s.x_start, s.x_end, s.y_start, s.y_end = int(x_start), int(x_end), int(y_start), int(y_end)
+    s.xs, s.ys = max(int(xs), 1), max(int(ys), 1)
+    s.jitter = int(bool(jitter))
+    s.seed = int(seed) & 0xFFFFFFFF
+    return s
+
+
+def sampler_desc_from_object(sampler, seed=0):
+    if type(sampler).__name__ != 'StratifiedSampler':
+        raise NotImplementedError('only StratifiedSampler is on the supported hot path')
+    if sampler.s_open != 0. or sampler.s_close != 0.:
+        raise NotImplementedError('shutter intervals (motion blur) are outside the supported hot path')
+    return sampler_desc(sampler.xPixel_start, sampler.xPixel_end, sampler.yPixel_start, sampler.yPixel_end,
+                        sampler.xSamples, sampler.ySamples, sampler.jitter, seed)
+
+
+def integrator_desc(kind, max_depth=5, pretest=False):
+    i = A.pt_integrator_desc()
+    i.kind, i.max_depth, i.pretest = int(kind), int(max_depth), int(bool(pretest))
+    return i
+
+
+def integrator_desc_from_object(integ, pretest=False):
+    nm = type(integ).__name__
+    if nm == 'DirectLightingIntegrator':
+        return integrator_desc(A.PT_INTEG_DIRECT, integ.max_depth, pretest)
+    if nm == 'PathIntegrator':
+        return integrator_desc(A.PT_INTEG_PATH, integ.max_depth, pretest)
+    raise NotImplementedError('integrator %s is outside the supported hot path' % nm)
+
+
+def tile_desc(x0, x1, y0, y1, s0, s1):
+    t = A.pt_tile()
+    t.x0, t.x1, t.y0, t.y1, t.s0, t.s1 = int(x0), int(x1), int(y0), int(y1), int(s0), int(s1)
+    return t

@@ -1,0 +1,116 @@
+"""ctypes loader for oracle/liboracle.so — the CPU checker (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pytracer_amd import _abi as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'oracle', 'pt_oracle.c')
+LIB = os.path.join(ROOT, 'oracle', 'liboracle.so')
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle'), 'liboracle.so'])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        L.pto_hash_uniform.restype = C.c_double
+        L.pto_hash_uniform.argtypes = [C.c_uint32, C.c_uint32]
+        L.pto_scene_create.argtypes = [C.POINTER(A.pt_scene_desc), C.POINTER(C.c_void_p)]
+        L.pto_scene_destroy.argtypes = [C.c_void_p]
+        L.pto_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.POINTER(A.pt_stats)]
+        L.pto_table_dims.argtypes = [C.c_void_p, C.POINTER(A.pt_integrator_desc)]
+        L.pto_render.argtypes = [C.c_void_p, C.POINTER(A.pt_camera), C.POINTER(A.pt_film_desc),
+                                 C.POINTER(A.pt_sampler_desc), C.POINTER(A.pt_integrator_desc), C.POINTER(A.pt_tile),
+                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(A.pt_stats)]
+        L.pto_film_resolve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.pto_camera_rays.argtypes = [C.POINTER(A.pt_camera), C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+        L.pto_hit_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                       C.c_void_p]
+        L.pto_sample_l.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class OracleScene(object):
+    def __init__(self, flat):
+        self.flat = flat
+        self._h = C.c_void_p()
+        d = flat.desc()
+        rc = lib().pto_scene_create(C.byref(d), C.byref(self._h))
+        assert rc == 0, rc
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            lib().pto_scene_destroy(self._h)
+            self._h = None
+
+    def intersect(self, rays8n, any_hit=False, stats=None):
+        """rays8n: float64 [8][n] component-major.  Returns prim, t, b1, b2."""
+        rays = np.ascontiguousarray(rays8n, np.float64)
+        n = rays.shape[1]
+        prim = np.empty(n, np.int32)
+        t = np.empty(n)
+        b1 = np.empty(n)
+        b2 = np.empty(n)
+        rc = lib().pto_intersect(self._h, rays.ctypes.data, n, int(any_hit), prim.ctypes.data, t.ctypes.data,
+                                 b1.ctypes.data, b2.ctypes.data, C.byref(stats) if stats is not None else None)
+        assert rc == 0, rc
+        return prim, t, b1, b2
+
+    def render(self, cam, film, sampler, integ, tile, table=None, stats=None, want_L=True):
+        n = (tile.x1 - tile.x0) * (tile.y1 - tile.y0) * (tile.s1 - tile.s0)
+        acc = np.zeros((film.y_cnt, film.x_cnt, 4))
+        L = np.zeros((n, 3)) if want_L else None
+        dims = 0
+        tptr = None
+        if table is not None:
+            table = np.ascontiguousarray(table, np.float64)
+            dims = table.shape[1]
+            tptr = table.ctypes.data
+        rc = lib().pto_render(self._h, C.byref(cam), C.byref(film), C.byref(sampler), C.byref(integ), C.byref(tile),
+                              tptr, dims, acc.ctypes.data, L.ctypes.data if want_L else None,
+                              C.byref(stats) if stats is not None else None)
+        assert rc == 0, rc
+        return acc, L
+
+    def hit_geometry(self, ray8, prim, t, b1, b2):
+        out = np.empty(15)
+        r = np.ascontiguousarray(ray8, np.float64)
+        lib().pto_hit_geometry(self._h, r.ctypes.data, int(prim), float(t), float(b1), float(b2), out.ctypes.data)
+        return out
+
+    def sample_l(self, light, p, pEps, u1, u2):
+        out = np.empty(18)
+        pp = np.ascontiguousarray(p, np.float64)
+        lib().pto_sample_l(self._h, int(light), pp.ctypes.data, float(pEps), float(u1), float(u2), out.ctypes.data)
+        return out
+
+
+def camera_rays(cam, table):
+    table = np.ascontiguousarray(table, np.float64)
+    out = np.empty((len(table), 6))
+    lib().pto_camera_rays(C.byref(cam), table.ctypes.data, table.shape[1], len(table), out.ctypes.data)
+    return out
+
+
+def film_resolve(acc):
+    acc = np.ascontiguousarray(acc, np.float64)
+    rgb = np.empty(acc.shape[:2] + (3,))
+    lib().pto_film_resolve(acc.ctypes.data, acc.shape[1], acc.shape[0], rgb.ctypes.data)
+    return rgb

@@ -1,0 +1,173 @@
+"""Pins the CPU oracle (oracle/pt_oracle.c) to the reference: every fixture under
+tests/golden was produced by running the reference pyTracer itself
+(tools/oracle/gen_fixtures.py).  Discrete results (hit flag, primitive index) must be
+bit-exact; continuous ones agree to 1e-9 relative (the reference's ndarray.dot may fuse
+multiply-adds, np.roots is replaced by the closed form)."""
+import os
+
+import numpy as np
+import pytest
+
+import pytracer_amd as pa
+from pytracer_amd import _abi as A
+import oracle_lib as O
+
+RTOL = 1e-9
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+@pytest.fixture(scope='module')
+def head(golden_dir):
+    d = load(golden_dir, 'head_mesh_scene.npz')
+    flat = pa.flat_scene_from_npz(d)
+    return d, flat, O.OracleScene(flat)
+
+
+def test_hash_uniform_matches_generator():
+    # tools/oracle/gen_fixtures.py:hash_uniform, restated here in python ints
+    M = (1 << 64) - 1
+
+    def h(sid, k):
+        z = ((sid & 0xFFFFFFFF) << 32 | (k & 0xFFFFFFFF)) & M
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z = z ^ (z >> 31)
+        return (z >> 11) * (1.0 / 9007199254740992.0)
+    for sid, k in [(0, 0), (1, 0), (0, 1), (12345, 7), (2 ** 32 - 1, 2 ** 32 - 1), (4095, 20)]:
+        assert O.lib().pto_hash_uniform(sid, k) == h(sid, k)
+
+
+def test_head_scene_shape(head):
+    d, flat, _ = head
+    # 2 776 head + 2 backdrop triangles, 5 537 nodes
+    assert flat.n_tris == 2778 and flat.n_nodes == 5537
+    assert [len(l) for l in flat.material_lobes] in ([3, 1], [1, 3])
+    uber = max(flat.material_lobes, key=len)
+    assert [l[0] for l in uber] == [A.PT_LOBE_LAMBERT, A.PT_LOBE_MICROFACET_BLINN, A.PT_LOBE_SPEC_TRANSMIT]
+    assert uber[1][4] == pytest.approx(10.0)      # Blinn(1/0.1)
+
+
+def rays_from_log(log):
+    r = np.empty((8, len(log)))
+    r[0:6] = log[:, 2:8].T
+    r[6] = log[:, 8]
+    r[7] = log[:, 9]
+    return r
+
+
+@pytest.mark.parametrize('name', ['head_direct_40x40x1.npz', 'head_direct_24x24x4.npz', 'head_path_32x32x4.npz',
+                                  'head_c1_window.npz'])
+def test_logged_rays_bit_exact(golden_dir, head, name):
+    """Every ray the reference traced while rendering (camera pre-tests, closest hits,
+    shadow rays, bounce rays): same hit flag and same index into BVH.primitives."""
+    _, _, osc = head
+    d = load(golden_dir, name)
+    log, res, geo = d['log_rays'], d['log_rres'], d['log_hitgeo']
+    kind = log[:, 1].astype(int)
+    rays = rays_from_log(log)
+    for any_hit in (0, 1):
+        sel = np.nonzero(kind == any_hit)[0]
+        assert len(sel) > 100
+        prim, t, b1, b2 = osc.intersect(rays[:, sel], any_hit=bool(any_hit))
+        if any_hit:
+            assert np.array_equal(prim, res[sel, 0].astype(np.int32))
+        else:
+            assert np.array_equal(prim >= 0, res[sel, 0] > 0)
+            assert np.array_equal(prim, res[sel, 1].astype(np.int32))
+            np.testing.assert_allclose(t, res[sel, 2], rtol=RTOL)
+            # hit geometry: p, nn, dpdu, dpdv, u, v, rEps
+            hit = np.nonzero(prim >= 0)[0][:300]
+            for i in hit:
+                g = osc.hit_geometry(rays[:, sel[i]], prim[i], t[i], b1[i], b2[i])
+                np.testing.assert_allclose(g, geo[sel[i]], rtol=RTOL, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', ['bvh_soup300.npz', 'bvh_soup2000.npz', 'bvh_soup500dup.npz'])
+def test_soup_rays_bit_exact(golden_dir, name):
+    """Random soups (incl. exact duplicate triangles → multi-primitive leaves, axis-parallel
+    rays → infinite inv_dir, finite maxt)."""
+    d = load(golden_dir, name)
+    flat = pa.flat_scene_from_npz(d)
+    osc = O.OracleScene(flat)
+    rays = np.ascontiguousarray(d['rays'].T)
+    prim, t, _, _ = osc.intersect(rays, any_hit=False)
+    assert np.array_equal(prim, d['res'][:, 1].astype(np.int32))
+    np.testing.assert_allclose(t, d['res'][:, 2], rtol=RTOL)
+    occ, _, _, _ = osc.intersect(rays, any_hit=True)
+    assert np.array_equal(occ, d['res'][:, 3].astype(np.int32))
+
+
+@pytest.mark.parametrize('name', ['head_direct_40x40x1.npz', 'head_path_32x32x4.npz'])
+def test_camera_rays(golden_dir, name):
+    d = load(golden_dir, name)
+    cam, _ = pa.camera_film_from_npz(d)
+    out = O.camera_rays(cam, d['samples'])
+    np.testing.assert_allclose(out, d['rays'][:, 0:6], rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize('name', ['head_direct_24x24x4.npz', 'head_path_32x32x4.npz'])
+def test_sample_l(golden_dir, head, name):
+    _, _, osc = head
+    d = load(golden_dir, name)
+    sl = d['log_sl']
+    assert len(sl) > 100
+    for row in sl[:400]:
+        out = osc.sample_l(0, row[0:3], row[3], row[4], row[5])
+        np.testing.assert_allclose(out[0:7], row[7:14], rtol=RTOL, atol=1e-12)     # Li, wi, pdf
+        np.testing.assert_allclose(out[7:15], row[14:22], rtol=RTOL, atol=1e-12)   # shadow ray
+
+
+def render_fixture(osc, d, integ):
+    cam, film = pa.camera_film_from_npz(d)
+    sub = d['sub']
+    smp = pa.sampler_desc(sub[0], sub[1], sub[2], sub[3], d['spp'][0], d['spp'][1], True, 0)
+    tile = pa.tile_desc(sub[0], sub[1], sub[2], sub[3], 0, int(d['spp'][0] * d['spp'][1]))
+    st = A.pt_stats()
+    acc, L = osc.render(cam, film, smp, integ, tile, table=d['samples'], stats=st)
+    return acc, L, st
+
+
+@pytest.mark.parametrize('name,kind', [('head_direct_40x40x1.npz', A.PT_INTEG_DIRECT),
+                                       ('head_direct_24x24x4.npz', A.PT_INTEG_DIRECT),
+                                       ('head_c1_window.npz', A.PT_INTEG_DIRECT),
+                                       ('head_path_32x32x4.npz', A.PT_INTEG_PATH)])
+def test_render_matches_reference(golden_dir, head, name, kind):
+    """Per-sample radiance (after the renderer's guards), film accumulators and resolved rgb
+    against the reference render on the captured sample stream + injected counter rng."""
+    _, flat, osc = head
+    d = load(golden_dir, name)
+    assert d['samples'].shape[1] == flat.table_dims(kind)
+    acc, L, st = render_fixture(osc, d, pa.integrator_desc(kind, 5, pretest=True))
+    ref = d['L']
+    scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-12)
+    err = np.abs(L - ref) / scale
+    assert err.max() < 1e-8, (err.max(), int(err.argmax()) // 3)
+    np.testing.assert_allclose(acc[..., 0:3], d['film_Lxyz'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(acc[..., 3], d['film_wsum'], rtol=1e-10, atol=1e-12)
+    # ray census equals the reference's: one any-hit pre-test + the rays logged
+    kinds = d['log_rays'][:, 1].astype(int)
+    if kind == A.PT_INTEG_PATH:
+        assert st.rays_closest == int((kinds == 0).sum())
+        assert st.rays_any == int((kinds == 1).sum())
+    # tone-mapped 8-bit image of imageio.write_image (per-channel max → 255)
+    rgb = O.film_resolve(acc)
+    img = rgb.copy()
+    for c in range(3):
+        m = img[:, :, c].max()
+        if m != 0:
+            img[:, :, c] = 255. * img[:, :, c] / m
+    diff = np.abs(img.astype('uint8').astype(int) - d['img8'].astype(int))
+    assert diff.max() <= 1
+
+
+def test_pretest_flag_does_not_change_image(golden_dir, head):
+    _, _, osc = head
+    d = load(golden_dir, 'head_direct_40x40x1.npz')
+    a0, L0, s0 = render_fixture(osc, d, pa.integrator_desc(A.PT_INTEG_DIRECT, 5, pretest=False))
+    a1, L1, s1 = render_fixture(osc, d, pa.integrator_desc(A.PT_INTEG_DIRECT, 5, pretest=True))
+    assert np.array_equal(L0, L1) and np.array_equal(a0, a1)
+    assert s1.rays_any == s0.rays_any + s0.camera_samples
