@@ -1,0 +1,438 @@
+// pt_api.hip — the C ABI of include/pytracer_hip.h: context, scene upload, batched
+// intersection, the wavefront render loop and film resolve.  Host code only launches the
+// kernels of pt_kernels.hip; there is no CPU fallback anywhere in this library.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "pt_kernels.h"
+
+struct pt_ctx {
+    int device;
+    char err[512];
+    // scene (device)
+    bool have_scene;
+    DScene sc;
+    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights;
+    int stack_need;          // deepest leaf = max simultaneous todo entries (bvh.py:332 allows 64)
+    bool has_spec_reflect;   // any material with a SpecularReflection lobe (Direct recursion)
+    int light_ns[16];
+    int shadow_per_vertex_direct;
+    // workspace (device), sized for `cap` paths per batch
+    long cap, sh_cap;
+    void *ws;
+    size_t ws_bytes;
+    Queue q[2];
+    ShadowQueue sh;
+    PathState st;
+    int *d_counts;           // [3]: q0, q1, shadow
+    RenderConst *d_rc;
+    unsigned long long *d_counters;
+    int n_cu;
+};
+
+static int fail(pt_ctx *c, int code, const char *fmt, ...) {
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof(c->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(c, PT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" int pt_version(void) { return PT_ABI_VERSION; }
+
+static char g_create_err[512] = "null context";
+
+extern "C" const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+#define CREATE_CHK(call)                                                                               \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            snprintf(g_create_err, sizeof(g_create_err), "%s failed: %s", #call, hipGetErrorString(e_)); \
+            if (c) free(c);                                                                            \
+            return PT_ERR_HIP;                                                                         \
+        }                                                                                              \
+    } while (0)
+
+extern "C" int pt_ctx_create(int device, pt_ctx **out) {
+    if (!out) return PT_ERR_ARG;
+    *out = nullptr;
+    pt_ctx *c = nullptr;
+    int ndev = 0;
+    CREATE_CHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        snprintf(g_create_err, sizeof(g_create_err), "device %d out of range (%d visible)", device, ndev);
+        return PT_ERR_ARG;
+    }
+    c = (pt_ctx *)calloc(1, sizeof(pt_ctx));
+    if (!c) return PT_ERR_ARG;
+    c->device = device;
+    CREATE_CHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CREATE_CHK(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CREATE_CHK(hipMalloc((void **)&c->d_counts, 3 * sizeof(int)));
+    CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
+    CREATE_CHK(hipMalloc((void **)&c->d_counters, CNT_COUNT * sizeof(unsigned long long)));
+    *out = c;
+    return PT_OK;
+}
+
+static void free_scene(pt_ctx *c) {
+    void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights};
+    for (void **p : ps) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    c->have_scene = false;
+}
+
+extern "C" int pt_ctx_destroy(pt_ctx *c) {
+    if (!c) return PT_OK;
+    (void)hipSetDevice(c->device);
+    free_scene(c);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_rc) (void)hipFree(c->d_rc);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    free(c);
+    return PT_OK;
+}
+
+// Validates every index the kernels dereference and measures the deepest leaf.
+static int check_tree(pt_ctx *c, const pt_scene_desc *d, int *max_depth) {
+    const int n = d->n_nodes, p = d->n_tris;
+    *max_depth = 0;
+    if (n == 0) return PT_OK;
+    std::vector<int> stack_node, stack_depth;
+    std::vector<char> seen((size_t)n, 0);
+    stack_node.push_back(0);
+    stack_depth.push_back(0);
+    long visited = 0;
+    while (!stack_node.empty()) {
+        int i = stack_node.back(), dep = stack_depth.back();
+        stack_node.pop_back();
+        stack_depth.pop_back();
+        if (i < 0 || i >= n) return fail(c, PT_ERR_ARG, "node index %d out of range", i);
+        if (seen[i]) return fail(c, PT_ERR_ARG, "node %d reachable twice (not a tree)", i);
+        seen[i] = 1;
+        visited++;
+        const int32_t *m = d->node_meta + 3 * (size_t)i;
+        if (m[1] < 0 || m[1] > 0xFFFF) return fail(c, PT_ERR_ARG, "node %d: n_prim %d out of range", i, m[1]);
+        if (m[1] > 0) {
+            if (m[0] < 0 || (long)m[0] + m[1] > p) return fail(c, PT_ERR_ARG, "leaf %d: primitive range out of bounds", i);
+            *max_depth = std::max(*max_depth, dep);
+        } else {
+            if (m[2] < 0 || m[2] > 2) return fail(c, PT_ERR_ARG, "node %d: axis %d", i, m[2]);
+            if (i + 1 >= n || m[0] <= i || m[0] >= n) return fail(c, PT_ERR_ARG, "node %d: child out of range", i);
+            stack_node.push_back(i + 1); stack_depth.push_back(dep + 1);
+            stack_node.push_back(m[0]); stack_depth.push_back(dep + 1);
+        }
+    }
+    (void)visited;
+    return PT_OK;
+}
+
+template <typename T>
+static hipError_t upload(void **dst, const T *src, size_t count) {
+    *dst = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    if (count) e = hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
+    if (!c || !d) return PT_ERR_ARG;
+    if (d->n_nodes < 0 || d->n_tris < 0 || d->n_materials < 0 || d->n_lights < 0) return fail(c, PT_ERR_ARG, "negative count");
+    if ((d->n_nodes && (!d->node_bounds || !d->node_meta)) ||
+        (d->n_tris && (!d->tri_verts || !d->tri_mat || !d->tri_flip)) || (d->n_materials && !d->materials) ||
+        (d->n_lights && !d->lights))
+        return fail(c, PT_ERR_ARG, "null array");
+    if (d->n_lights > 16) return fail(c, PT_ERR_CAPACITY, "at most 16 lights");
+    HIPCHK(c, hipSetDevice(c->device));
+    int depth = 0;
+    int rc = check_tree(c, d, &depth);
+    if (rc != PT_OK) return rc;
+    if (depth > 64) return fail(c, PT_ERR_DEPTH, "BVH leaf depth %d exceeds the 64-entry todo stack (bvh.py:332)", depth);
+    for (int i = 0; i < d->n_tris; i++)
+        if (d->tri_mat[i] < 0 || d->tri_mat[i] >= d->n_materials) return fail(c, PT_ERR_ARG, "triangle %d: material index", i);
+    bool spec = false;
+    for (int i = 0; i < d->n_materials; i++) {
+        const pt_material &m = d->materials[i];
+        if (m.n_lobes < 0 || m.n_lobes > PT_MAX_LOBES) return fail(c, PT_ERR_ARG, "material %d: n_lobes", i);
+        for (int k = 0; k < m.n_lobes; k++) {
+            if (m.lobes[k].type < 0 || m.lobes[k].type > PT_LOBE_SPEC_TRANSMIT) return fail(c, PT_ERR_ARG, "material %d: lobe type", i);
+            spec |= m.lobes[k].type == PT_LOBE_SPEC_REFLECT;
+        }
+    }
+    int spv = 0;
+    double le[3] = {0, 0, 0};
+    for (int i = 0; i < d->n_lights; i++) {
+        const pt_light &l = d->lights[i];
+        if (l.kind < 0 || l.kind > PT_LIGHT_POINT) return fail(c, PT_ERR_ARG, "light %d: kind", i);
+        if (l.ns < 1 || l.ns > 16) return fail(c, PT_ERR_CAPACITY, "light %d: ns must be in 1..16", i);
+        c->light_ns[i] = l.ns;
+        spv += l.ns;
+        if (l.kind == PT_LIGHT_DIFFUSE_SPHERE) for (int k = 0; k < 3; k++) le[k] += l.emit[k];
+    }
+    free_scene(c);
+    // build the device records
+    std::vector<GNode> nodes((size_t)d->n_nodes);
+    for (int i = 0; i < d->n_nodes; i++) {
+        GNode &g = nodes[i];
+        memcpy(g.bmin, d->node_bounds + 6 * (size_t)i, 3 * sizeof(double));
+        memcpy(g.bmax, d->node_bounds + 6 * (size_t)i + 3, 3 * sizeof(double));
+        const int32_t *m = d->node_meta + 3 * (size_t)i;
+        g.offset = m[0];
+        g.nprim_axis = m[1] | (m[2] << 16);
+        g._pad = 0;
+    }
+    std::vector<GTri> tris((size_t)d->n_tris);
+    for (int i = 0; i < d->n_tris; i++) {
+        const double *v = d->tri_verts + 9 * (size_t)i;
+        GTri &g = tris[i];
+        for (int k = 0; k < 3; k++) {
+            g.p1[k] = v[k];
+            g.e1[k] = v[3 + k] - v[k];   // e1 = p2 - p1, triangle.py:183
+            g.e2[k] = v[6 + k] - v[k];   // e2 = p3 - p1, triangle.py:184
+        }
+        g._pad = 0;
+    }
+    HIPCHK(c, upload(&c->d_nodes, nodes.data(), nodes.size()));
+    HIPCHK(c, upload(&c->d_tris, tris.data(), tris.size()));
+    HIPCHK(c, upload(&c->d_verts, d->tri_verts, 9 * (size_t)d->n_tris));
+    HIPCHK(c, upload(&c->d_mat, d->tri_mat, (size_t)d->n_tris));
+    HIPCHK(c, upload(&c->d_flip, d->tri_flip, (size_t)d->n_tris));
+    HIPCHK(c, upload(&c->d_mats, d->materials, (size_t)d->n_materials));
+    HIPCHK(c, upload(&c->d_lights, d->lights, (size_t)d->n_lights));
+    DScene &s = c->sc;
+    s.nodes = (const GNode *)c->d_nodes;
+    s.tris = (const GTri *)c->d_tris;
+    s.tri_verts = (const double *)c->d_verts;
+    s.tri_mat = (const int32_t *)c->d_mat;
+    s.tri_flip = (const int32_t *)c->d_flip;
+    s.mats = (const pt_material *)c->d_mats;
+    s.lights = (const pt_light *)c->d_lights;
+    s.n_nodes = d->n_nodes; s.n_tris = d->n_tris; s.n_mats = d->n_materials; s.n_lights = d->n_lights;
+    memcpy(s.le_sum, le, sizeof(le));
+    c->stack_need = std::max(depth, 1);
+    c->has_spec_reflect = spec;
+    c->shadow_per_vertex_direct = spv;
+    c->have_scene = true;
+    return PT_OK;
+}
+
+static int trace_grid(const pt_ctx *c, long n) {
+    long blocks = (n + PT_BLOCK - 1) / PT_BLOCK;
+    long cap = (long)c->n_cu * 8;
+    return (int)std::max<long>(1, std::min(blocks, cap));
+}
+
+static int read_counters(pt_ctx *c, hipStream_t stream, pt_stats *stats) {
+    unsigned long long h[CNT_COUNT];
+    HIPCHK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIPCHK(c, hipStreamSynchronize(stream));
+    stats->node_visits += h[CNT_NODE_VISITS];
+    stats->tri_tests += h[CNT_TRI_TESTS];
+    stats->rays_closest += h[CNT_RAYS_CLOSEST];
+    stats->rays_any += h[CNT_RAYS_ANY];
+    stats->camera_samples += h[CNT_CAMERA_SAMPLES];
+    stats->guard_nan += h[CNT_GUARD_NAN];
+    stats->guard_neg += h[CNT_GUARD_NEG];
+    stats->guard_inf += h[CNT_GUARD_INF];
+    return PT_OK;
+}
+
+extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hit, int32_t *prim, double *t,
+                            double *b1, double *b2, pt_stats *stats, void *stream_) {
+    if (!c) return PT_ERR_ARG;
+    if (!c->have_scene) return fail(c, PT_ERR_NO_SCENE, "pt_intersect before pt_scene_upload");
+    if (n < 0 || n > 0x7FFFFFFF) return fail(c, PT_ERR_ARG, "ray count %lld out of range", (long long)n);
+    if (n == 0) return PT_OK;
+    if (!rays || !prim) return fail(c, PT_ERR_ARG, "null rays/prim");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long *cnt = nullptr;
+    if (stats) {
+        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, CNT_COUNT * sizeof(unsigned long long), stream));
+        cnt = c->d_counters;
+    }
+    ShadowResolve rs = {nullptr, 0, nullptr, nullptr, 0};
+    HIPCHK(c, pt_launch_trace(any_hit != 0, c->stack_need, trace_grid(c, n), stream, c->sc, rays, (long)n, nullptr,
+                              (int)n, prim, t, b1, b2, rs, cnt));
+    if (stats) return read_counters(c, stream, stats);
+    return PT_OK;
+}
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// carve the wavefront workspace: two ray queues, the shadow queue and the path state
+static int ensure_workspace(pt_ctx *c, long cap, long sh_cap) {
+    if (c->ws && c->cap >= cap && c->sh_cap >= sh_cap) return PT_OK;
+    if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; }
+    size_t bytes = 0;
+    auto need = [&](size_t b) { size_t off = bytes; bytes += align_up(b); return off; };
+    size_t off_q[2][6];
+    for (int k = 0; k < 2; k++) {
+        off_q[k][0] = need(8 * cap * sizeof(double));
+        off_q[k][1] = need(cap * sizeof(int));
+        off_q[k][2] = need(cap * sizeof(int));
+        off_q[k][3] = need(cap * sizeof(double));
+        off_q[k][4] = need(cap * sizeof(double));
+        off_q[k][5] = need(cap * sizeof(double));
+    }
+    size_t off_sr = need(8 * sh_cap * sizeof(double)), off_sc = need(3 * sh_cap * sizeof(double));
+    size_t off_ss = need(sh_cap * sizeof(int));
+    size_t off_T = need(3 * cap * sizeof(double)), off_L = need(3 * cap * sizeof(double));
+    size_t off_img = need(2 * cap * sizeof(double));
+    HIPCHK(c, hipMalloc(&c->ws, bytes));
+    char *b = (char *)c->ws;
+    for (int k = 0; k < 2; k++) {
+        Queue &q = c->q[k];
+        q.rays = (double *)(b + off_q[k][0]); q.stride = cap;
+        q.slot = (int *)(b + off_q[k][1]); q.prim = (int *)(b + off_q[k][2]);
+        q.t = (double *)(b + off_q[k][3]); q.b1 = (double *)(b + off_q[k][4]); q.b2 = (double *)(b + off_q[k][5]);
+        q.count = c->d_counts + k;
+    }
+    c->sh.rays = (double *)(b + off_sr); c->sh.c = (double *)(b + off_sc); c->sh.slot = (int *)(b + off_ss);
+    c->sh.stride = sh_cap; c->sh.count = c->d_counts + 2;
+    c->st.T = (double *)(b + off_T); c->st.L = (double *)(b + off_L); c->st.img = (double *)(b + off_img);
+    c->st.stride = cap;
+    c->cap = cap; c->sh_cap = sh_cap; c->ws_bytes = bytes;
+    return PT_OK;
+}
+
+static int make_layout(const pt_ctx *c, const pt_integrator_desc *ig, Layout *L) {
+    memset(L, 0, sizeof(*L));
+    const int nl = c->sc.n_lights;
+    if (ig->kind == PT_INTEG_DIRECT) {
+        int n1 = 0;
+        for (int i = 0; i < nl; i++) n1 += 2 * c->light_ns[i];
+        int o2 = 5 + n1;
+        for (int i = 0; i < nl; i++) {      // direct.py:54-60: LightSampleOffset then BSDFSampleOffset per light
+            const int ns = c->light_ns[i];
+            L->d_ns[i] = ns;
+            L->d_lpos[i] = o2; o2 += 2 * ns;   // light u_pos
+            o2 += 2 * ns;                      // bsdf u_dir (only read by the dead branch of estimate_direct)
+        }
+        L->dims = 5 + n1 + 2 * n1;
+    } else {
+        int o1 = 5, o2 = 5 + 12;
+        for (int i = 0; i < 3; i++) {       // path.py:38-42
+            o1++;                            // light u_com (one shape per light: unused)
+            L->p_lpos[i] = o2; o2 += 2;
+            L->p_lnum[i] = o1++;
+            o1++; o2 += 2;                   // bsdf sample of estimate_direct (dead branch)
+            L->p_pcom[i] = o1++;
+            L->p_pdir[i] = o2; o2 += 2;
+        }
+        L->dims = 35;
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *film, const pt_sampler_desc *sp,
+                         const pt_integrator_desc *ig, const pt_tile *tile, const double *sample_table,
+                         int32_t table_dims, double *film_accum, double *sample_L, pt_stats *stats, void *stream_) {
+    if (!c) return PT_ERR_ARG;
+    if (!c->have_scene) return fail(c, PT_ERR_NO_SCENE, "pt_render before pt_scene_upload");
+    if (!cam || !film || !sp || !ig || !tile) return fail(c, PT_ERR_ARG, "null descriptor");
+    if (ig->kind != PT_INTEG_DIRECT && ig->kind != PT_INTEG_PATH) return fail(c, PT_ERR_ARG, "integrator kind %d", ig->kind);
+    if (ig->max_depth < 0 || ig->max_depth > 64) return fail(c, PT_ERR_ARG, "max_depth %d", ig->max_depth);
+    if (sp->xs < 1 || sp->ys < 1 || sp->x_end < sp->x_start || sp->y_end < sp->y_start) return fail(c, PT_ERR_ARG, "sampler window");
+    const int spp = sp->xs * sp->ys;
+    if (tile->x0 < sp->x_start || tile->x1 > sp->x_end || tile->y0 < sp->y_start || tile->y1 > sp->y_end ||
+        tile->x1 < tile->x0 || tile->y1 < tile->y0 || tile->s0 < 0 || tile->s1 > spp || tile->s1 < tile->s0)
+        return fail(c, PT_ERR_ARG, "tile outside the sampler window");
+    if (film->x_cnt < 1 || film->y_cnt < 1 || !(film->xw > 0.) || !(film->yw > 0.)) return fail(c, PT_ERR_ARG, "film");
+    const long window = (long)(sp->x_end - sp->x_start) * (sp->y_end - sp->y_start) * spp;
+    if (window > 0xFFFFFFFFl) return fail(c, PT_ERR_CAPACITY, "more than 2^32 samples in the sampler window");
+    RenderConst h;
+    memset(&h, 0, sizeof(h));
+    h.cam = *cam; h.film = *film; h.sp = *sp; h.ig = *ig; h.tile = *tile;
+    make_layout(c, ig, &h.lay);
+    h.table = sample_table;
+    if (sample_table && table_dims != h.lay.dims)
+        return fail(c, PT_ERR_ARG, "sample table has %d dims, this scene/integrator needs %d", table_dims, h.lay.dims);
+    const long total = (long)(tile->x1 - tile->x0) * (tile->y1 - tile->y0) * (tile->s1 - tile->s0);
+    if (total == 0) return PT_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(c, hipSetDevice(c->device));
+
+    long batch = 1l << 22;
+    if (const char *e = getenv("PT_BATCH")) { long v = atol(e); if (v >= 64) batch = v; }
+    batch = std::min(batch, total);
+    batch = (batch + 63) & ~63l;
+    const int spv = ig->kind == PT_INTEG_DIRECT ? std::max(c->shadow_per_vertex_direct, 1) : 1;
+    int rc = ensure_workspace(c, batch, batch * spv);
+    if (rc != PT_OK) return rc;
+
+    HIPCHK(c, hipMemcpyAsync(c->d_rc, &h, sizeof(h), hipMemcpyHostToDevice, stream));
+    unsigned long long *cnt = nullptr;
+    if (stats) {
+        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, CNT_COUNT * sizeof(unsigned long long), stream));
+        cnt = c->d_counters;
+    }
+    // number of shade levels: Path shades bounce 0..max_depth; Direct recurses only through
+    // specular reflection (depth+1 < max_depth)
+    int levels;
+    if (ig->kind == PT_INTEG_PATH) levels = ig->max_depth + 1;
+    else levels = c->has_spec_reflect ? std::max(ig->max_depth, 1) : 1;
+
+    const ShadowResolve no_rs = {nullptr, 0, nullptr, nullptr, 0};
+    for (long base = 0; base < total; base += batch) {
+        const int nb = (int)std::min(batch, total - base);
+        const int g = (nb + PT_BLOCK - 1) / PT_BLOCK;
+        const int gt = trace_grid(c, nb);
+        HIPCHK(c, pt_launch_raygen(g, stream, c->d_rc, base, nb, c->q[0], c->st, cnt));
+        HIPCHK(c, pt_launch_set_int(stream, c->q[0].count, nb));
+        if (ig->pretest)   // renderer.py:168: same hit flag as the closest-hit pass below
+            HIPCHK(c, pt_launch_trace(true, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
+                                      nb, nullptr, nullptr, nullptr, nullptr, no_rs, cnt));
+        HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr, nb,
+                                  c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
+        int cur = 0;
+        for (int level = 0; level < levels; level++) {
+            Queue &qin = c->q[cur], &qout = c->q[cur ^ 1];
+            HIPCHK(c, hipMemsetAsync(qout.count, 0, sizeof(int), stream));
+            HIPCHK(c, hipMemsetAsync(c->sh.count, 0, sizeof(int), stream));
+            HIPCHK(c, pt_launch_shade(ig->kind, gt, stream, c->sc, c->d_rc, base, level, qin, qout, c->sh, c->st));
+            ShadowResolve rs = {c->sh.c, c->sh.stride, c->sh.slot, c->st.L, c->st.stride};
+            HIPCHK(c, pt_launch_trace(true, c->stack_need, trace_grid(c, (long)nb * spv), stream, c->sc, c->sh.rays,
+                                      c->sh.stride, c->sh.count, 0, nullptr, nullptr, nullptr, nullptr, rs, cnt));
+            if (level + 1 < levels) {
+                HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, qout.rays, qout.stride, qout.count,
+                                          0, qout.prim, qout.t, qout.b1, qout.b2, no_rs, cnt));
+                cur ^= 1;
+            }
+        }
+        HIPCHK(c, pt_launch_splat(g, stream, c->d_rc, nb, c->st, film_accum, sample_L, base, cnt));
+    }
+    if (stats) return read_counters(c, stream, stats);
+    return PT_OK;
+}
+
+extern "C" int pt_film_resolve(pt_ctx *c, const double *film_accum, int32_t x_cnt, int32_t y_cnt, double *rgb,
+                               void *stream_) {
+    if (!c) return PT_ERR_ARG;
+    if (!film_accum || !rgb || x_cnt < 0 || y_cnt < 0) return fail(c, PT_ERR_ARG, "film_resolve arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, pt_launch_film_resolve((hipStream_t)stream_, film_accum, (long)x_cnt * y_cnt, rgb));
+    return PT_OK;
+}

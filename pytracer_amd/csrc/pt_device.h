@@ -1,0 +1,557 @@
+// pt_device.h — device-side value types and the per-vertex shading math of the HIP back end.
+//
+// gfx950 only.  All arithmetic is binary64 and this translation unit is compiled with
+// -ffp-contract=off: the reference computes in numpy.float64 and hit/miss decisions must
+// reproduce it bit-exactly (include/pytracer_hip.h), so expressions are evaluated as
+// written, in the reference's operation order.  Each function cites the reference
+// file:line it restates (paths relative to the reference root).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pytracer_hip.h"
+
+#define PT_EPS 1e-5
+#define PT_PI 3.14159265358979323846
+#define PT_INV_PI (1.0 / PT_PI)
+#define PT_INV_2PI (1.0 / (2.0 * PT_PI))
+
+// BDFType bits, reflection/bdf/bdf.py:60-70
+#define BDF_REFLECTION 1u
+#define BDF_TRANSMISSION 2u
+#define BDF_DIFFUSE 4u
+#define BDF_GLOSSY 8u
+#define BDF_SPECULAR 16u
+#define BDF_ALL 31u
+
+struct d3 {
+    double x, y, z;
+};
+
+__device__ __forceinline__ d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 operator-(d3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ d3 operator*(d3 a, double s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ d3 operator*(d3 a, d3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ d3 operator/(d3 a, double s) { return mk3(a.x / s, a.y / s, a.z / s); }
+// ndarray.dot on 3-vectors: left-to-right accumulation
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// Vector.cross, geometry/__init__.py:79-82
+__device__ __forceinline__ d3 cross3(d3 a, d3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// sq_length / length, geometry/__init__.py:84-88
+__device__ __forceinline__ double sqlen3(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ double len3(d3 a) { return sqrt(sqlen3(a)); }
+// geometry/utility.py:55-73
+__device__ __forceinline__ d3 normalize3(d3 a) {
+    double l = len3(a);
+    if (!(l == 0.0)) return a / l;
+    return a;
+}
+__device__ __forceinline__ double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ double max0(double x) { return x > 0.0 ? x : 0.0; }
+
+// counter-based uniform in [0,1): splitmix64 finaliser of (sid, k); DESIGN.md "sample streams"
+__device__ __forceinline__ double hash_uniform(uint32_t sid, uint32_t k) {
+    uint64_t z = ((uint64_t)sid << 32) | (uint64_t)k;
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ uint32_t mix_seed(uint32_t sid, uint32_t seed) { return sid + seed * 0x9E3779B1u; }
+
+// ---------------------------------------------------------------------------------------
+// device scene layout (HBM).  Nodes and intersection triangles are 16-byte-aligned AoS
+// records fetched with dwordx4 loads by the one lane that walks them; everything indexed
+// by ray / path slot is component-major SoA so that a wave's 64 lanes read 512 contiguous
+// bytes per component.
+// ---------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) GNode {   // 64 B; bvh.py:60-66 _LinearNode
+    double bmin[3];
+    double bmax[3];
+    int32_t offset;      // interior: second child; leaf: first primitive
+    int32_t nprim_axis;  // n_prim | axis << 16
+    double _pad;
+};
+
+struct __attribute__((aligned(16))) GTri {    // 80 B; p1 and the two edges of triangle.py:183-184
+    double p1[3];
+    double e1[3];        // p2 - p1 (same subtraction, done once on the host in binary64)
+    double e2[3];        // p3 - p1
+    double _pad;
+};
+
+struct DScene {
+    const GNode *nodes;
+    const GTri *tris;
+    const double *tri_verts;   // [n_tris][9] p1,p2,p3 for shading geometry
+    const int32_t *tri_mat;
+    const int32_t *tri_flip;
+    const pt_material *mats;
+    const pt_light *lights;
+    int32_t n_nodes, n_tris, n_mats, n_lights;
+    double le_sum[3];          // Σ light.le over lights (DiffuseAreaLight.le = emit, light.py:503-505)
+};
+
+struct Ray {
+    d3 o, d;
+    double mint, maxt;
+};
+
+// ---------------------------------------------------------------------------------------
+// shading vertex: Triangle.intersect tail (shape/triangle.py:209-243, default uvs
+// (0,0),(1,0),(1,1) :125-127), DifferentialGeometry.__init__ (geometry/diffgeom.py:21-42),
+// BSDF.__init__ (reflection/bsdf.py:78-94).  Shading geometry == geometric (triangle.py:323-326).
+// ---------------------------------------------------------------------------------------
+struct Vertex {
+    d3 p, nn, sn, tn;
+    double rEps;
+    const pt_material *mat;
+};
+
+__device__ inline void make_vertex(const DScene &sc, const Ray &r, int prim, double t, Vertex &vx) {
+    const double *tv = sc.tri_verts + 9 * (size_t)prim;
+    d3 p1 = mk3(tv[0], tv[1], tv[2]), p2 = mk3(tv[3], tv[4], tv[5]), p3 = mk3(tv[6], tv[7], tv[8]);
+    const double du1 = 0. - 1., du2 = 1. - 1., dv1 = 0. - 1., dv2 = 0. - 1.;
+    d3 dp1 = p1 - p3, dp2 = p2 - p3;
+    double det = du1 * dv2 - du2 * dv1;
+    double detInv = 1.0 / det;
+    d3 dpdu = ((dp1 * dv2) - (dp2 * dv1)) * detInv;
+    d3 dpdv = ((dp1 * (-du2)) + (dp2 * du1)) * detInv;
+    vx.p = r.o + r.d * t;
+    vx.nn = normalize3(cross3(dpdu, dpdv));
+    if (sc.tri_flip[prim]) vx.nn = vx.nn * -1.0;
+    vx.rEps = 1e-3 * t;
+    vx.sn = normalize3(dpdu);
+    vx.tn = cross3(vx.nn, vx.sn);
+    vx.mat = sc.mats + sc.tri_mat[prim];
+}
+
+// BSDF.w2l, bsdf.py:187-194
+__device__ __forceinline__ d3 w2l(const Vertex &vx, d3 v) { return mk3(dot3(v, vx.sn), dot3(v, vx.tn), dot3(v, vx.nn)); }
+// BSDF.l2w AS WRITTEN, bsdf.py:196-205 (each basis vector scaled by the same component)
+__device__ __forceinline__ d3 l2w(const Vertex &vx, d3 v) {
+    return mk3(vx.sn.x * v.x + vx.tn.x * v.x + vx.nn.x * v.x, vx.sn.y * v.y + vx.tn.y * v.y + vx.nn.y * v.y,
+               vx.sn.z * v.z + vx.tn.z * v.z + vx.nn.z * v.z);
+}
+
+__device__ __forceinline__ unsigned lobe_flags(int type) {
+    // Lambertian/OrenNayar: REFLECTION|DIFFUSE; Microfacet: REFLECTION|GLOSSY;
+    // SpecularReflection: REFLECTION|SPECULAR; SpecularTransmission: TRANSMISSION|SPECULAR
+    const unsigned tab = (5u) | (5u << 5) | (9u << 10) | (17u << 15) | (18u << 20);
+    return (tab >> (5 * type)) & 31u;
+}
+// BDF.match_flag, bdf.py:166-170
+__device__ __forceinline__ bool match_flag(int type, unsigned flags) {
+    unsigned t = lobe_flags(type);
+    return (t & flags) == t;
+}
+
+// fr_diel AS WRITTEN, reflection/utility.py:46-57 (Q8)
+__device__ __forceinline__ double fr_diel(double cos_i, double cos_t, double eta_i, double eta_t) {
+    double r_para = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_t * cos_t));
+    double r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+    return .5 * (r_para * r_para + r_perp * r_perp);
+}
+// FresnelDielectric.__call__, reflection/fresnel.py:54-72
+__device__ inline double fresnel_dielectric(double cosi, double eta_i, double eta_t) {
+    double ci = clipd(cosi, -1., 1.);
+    double ei = eta_i, et = eta_t;
+    if (cosi < 0.) { double tmp = ei; ei = et; et = tmp; }
+    double st = ei / et * sqrt(max0(1. - ci * ci));
+    if (st >= 1.) return 1.;
+    double ct = sqrt(max0(1. - st * st));
+    return fr_diel(fabs(ci), ct, ei, et);
+}
+
+// reflection/utility.py:31-42
+__device__ __forceinline__ double sin_theta(d3 w) { return sqrt(max0(1. - w.z * w.z)); }
+__device__ __forceinline__ double cos_phi(d3 w) {
+    double s2 = max0(1. - w.z * w.z);
+    return s2 == 0. ? 1. : clipd(w.x / sqrt(s2), -1., 1.);
+}
+__device__ __forceinline__ double sin_phi(d3 w) {
+    double s2 = max0(1. - w.z * w.z);
+    return s2 == 0. ? 0. : clipd(w.y / sqrt(s2), -1., 1.);
+}
+
+// Blinn.pdf, reflection/bdf/torrance.py:95-102
+__device__ inline double blinn_pdf(double e, d3 wo, d3 wi) {
+    d3 wh = normalize3(wo + wi);
+    double ct = fabs(wh.z);
+    double dwh = dot3(wo, wh);
+    if (dwh <= 0.) return 0.;
+    return ((e + 1.) * pow(ct, e)) / (2. * PT_PI * 4. * dwh);
+}
+
+__device__ inline d3 lobe_f(const pt_lobe &l, d3 wo, d3 wi) {
+    d3 R = mk3(l.R[0], l.R[1], l.R[2]);
+    switch (l.type) {
+    case PT_LOBE_LAMBERT:   // bdf.py:327-332
+        return R * PT_INV_PI;
+    case PT_LOBE_OREN_NAYAR: {   // orennayar.py:44-62
+        double st_i = sin_theta(wi), st_o = sin_theta(wo);
+        double mc = 0.;
+        if (st_i > PT_EPS && st_o > PT_EPS) {
+            double dcos = cos_phi(wi) * cos_phi(wo) + sin_phi(wi) * sin_phi(wo);
+            mc = max0(dcos);
+        }
+        double sa, tb;
+        if (fabs(wi.z) > fabs(wo.z)) { sa = st_o; tb = st_i / fabs(wi.z); }
+        else { sa = st_i; tb = st_o / fabs(wo.z); }
+        return (R * PT_INV_PI) * (l.a + l.b * mc * sa * tb);
+    }
+    case PT_LOBE_MICROFACET_BLINN: {   // torrance.py:200-216, Blinn.D :69-70
+        double ct_i = wi.z, ct_o = wo.z;
+        if (ct_i == 0. || ct_o == 0.) return mk3(0, 0, 0);
+        d3 wh = normalize3(wi + wo);
+        double ct_h = dot3(wi, wh);
+        double F = fresnel_dielectric(ct_h, l.a, l.b);
+        double awh = fabs(wh.z), adot = fabs(dot3(wo, wh));
+        double g1 = 2. * awh * fabs(wo.z) / adot, g2 = 2. * awh * fabs(wi.z) / adot;
+        double gm = (g2 < g1) ? g2 : g1;
+        double G = (gm < 1.) ? gm : 1.;
+        double D = (l.c + 2) * PT_INV_2PI * pow(awh, l.c);
+        return (((R * D) * G) * F) / (4. * ct_i * ct_o);
+    }
+    default:   // specular lobes evaluate to 0, bdf.py:241-246,274-279
+        return mk3(0, 0, 0);
+    }
+}
+
+// BDF.pdf (bdf.py:97-106), Microfacet.pdf (torrance.py:225-228), specular → 0
+__device__ inline double lobe_pdf(const pt_lobe &l, d3 wo, d3 wi) {
+    switch (l.type) {
+    case PT_LOBE_LAMBERT:
+    case PT_LOBE_OREN_NAYAR:
+        return (wo.z * wi.z > 0.) ? fabs(wi.z) * PT_INV_PI : 0.;
+    case PT_LOBE_MICROFACET_BLINN:
+        if (wi.z * wo.z <= 0.) return 0.;
+        return blinn_pdf(l.c, wo, wi);
+    default:
+        return 0.;
+    }
+}
+
+__device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, double u2, d3 &wi_out, d3 &f_out) {
+    d3 R = mk3(l.R[0], l.R[1], l.R[2]);
+    switch (l.type) {
+    case PT_LOBE_LAMBERT:
+    case PT_LOBE_OREN_NAYAR: {
+        // BDF.sample_f (bdf.py:108-126); cosine_sample_hemisphere AS WRITTEN
+        // (montecarlo/utility.py:171-184 on top of uniform_sample_sphere :83-95; Q6)
+        double z = 1. - 2. * u1;
+        double r = sqrt(max0(1. - z * z));
+        double phi = 2. * PT_PI * u2;
+        d3 wi = mk3(r * cos(phi), r * sin(phi), z);
+        wi.z = sqrt(max0(1. - wi.x * wi.x - wi.y * wi.y));
+        if (wo.z < 0.) wi.z *= -1.;
+        wi_out = wi;
+        f_out = lobe_f(l, wo, wi);
+        return lobe_pdf(l, wo, wi);
+    }
+    case PT_LOBE_MICROFACET_BLINN: {   // torrance.py:218-223, Blinn.sample_f :72-93
+        double e = l.c;
+        double ct = pow(u1, 1. / (e + 1));
+        double st = sqrt(max0(1. - ct * ct));
+        double phi = u2 * 2. * PT_PI;
+        d3 wh = mk3(st * cos(phi), st * sin(phi), ct);
+        if (wo.z * wh.z <= 0.) wh = wh * -1.;
+        double dwh = dot3(wo, wh);
+        d3 wi = (-wo) + (wh * (2. * dwh));
+        double pdf = ((e + 1.) * pow(ct, e)) / (2. * PT_PI * 4. * dwh);
+        if (dwh <= 0.) pdf = 0.;
+        wi_out = wi;
+        if (wi.z * wo.z <= 0.) f_out = mk3(0, 0, 0);
+        else f_out = lobe_f(l, wo, wi);
+        return pdf;
+    }
+    case PT_LOBE_SPEC_REFLECT: {   // bdf.py:251-256
+        d3 wi = mk3(-wo.x, -wo.y, wo.z);
+        double F = (l.c != 0.) ? 1. : fresnel_dielectric(wo.z, l.a, l.b);
+        wi_out = wi;
+        f_out = (R * F) / fabs(wi.z);
+        return 1.;
+    }
+    default: {   // SpecularTransmission.sample_f, bdf.py:284-307
+        double ei = l.a, et = l.b;
+        if (wo.z > 0.) { double tmp = ei; ei = et; et = tmp; }
+        double si_sq = max0(1. - wo.z * wo.z);
+        double eta = ei / et;
+        double st_sq = eta * eta * si_sq;
+        if (st_sq >= 1.) return 0.;
+        double ct = sqrt(max0(1. - st_sq));
+        if (wo.z > 0.) ct = -ct;
+        d3 wi = mk3(eta * (-wo.x), eta * (-wo.y), ct);
+        double F = fresnel_dielectric(wo.z, l.a, l.b);
+        wi_out = wi;
+        f_out = (R * ((et * et) / (ei * ei) * (1. - F))) / fabs(wi.z);
+        return 1.;
+    }
+    }
+}
+
+// BSDF.f, bsdf.py:207-224
+__device__ inline d3 bsdf_f(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned flags) {
+    d3 wi = w2l(vx, wi_w), wo = w2l(vx, wo_w);
+    if (dot3(wi_w, vx.nn) * dot3(wo_w, vx.nn) > 0.) flags &= ~BDF_TRANSMISSION;
+    else flags &= ~BDF_REFLECTION;
+    d3 f = mk3(0, 0, 0);
+    for (int i = 0; i < vx.mat->n_lobes; i++)
+        if (match_flag(vx.mat->lobes[i].type, flags)) f = f + lobe_f(vx.mat->lobes[i], wo, wi);
+    return f;
+}
+
+// BSDF.pdf, bsdf.py:156-167
+__device__ inline double bsdf_pdf(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned flags) {
+    if (vx.mat->n_lobes == 0) return 0.;
+    d3 wo = w2l(vx, wo_w), wi = w2l(vx, wi_w);
+    double pdf = 0.;
+    int n_match = 0;
+    for (int i = 0; i < vx.mat->n_lobes; i++)
+        if (match_flag(vx.mat->lobes[i].type, flags)) { n_match++; pdf += lobe_pdf(vx.mat->lobes[i], wo, wi); }
+    return n_match > 0 ? pdf / n_match : 0.;
+}
+
+// BSDF.sample_f AS IT EXECUTES, bsdf.py:100-154: `bdf.type & SPECULAR` is an object, always
+// truthy, so the pdf sum (:132-135) and the f re-evaluation (:141-152) never run (Q2).
+__device__ inline double bsdf_sample_f(const Vertex &vx, d3 wo_w, double u0, double u1, double u_com, unsigned flags,
+                                       d3 &wi_w, d3 &f) {
+    const pt_material *m = vx.mat;
+    int n_match = 0;
+    for (int i = 0; i < m->n_lobes; i++) n_match += match_flag(m->lobes[i].type, flags) ? 1 : 0;
+    f = mk3(0, 0, 0);
+    wi_w = mk3(0, 0, 0);
+    if (n_match == 0) return 0.;
+    int cnt = (int)floor(u_com * n_match);
+    if (cnt > n_match - 1) cnt = n_match - 1;
+    int pick = -1;
+    for (int i = 0; i < m->n_lobes; i++)
+        if (match_flag(m->lobes[i].type, flags)) {
+            if (cnt == 0) { pick = i; break; }
+            cnt--;
+        }
+    if (pick < 0) return 0.;
+    d3 wo = w2l(vx, wo_w), wi, fl;
+    double pdf = lobe_sample_f(m->lobes[pick], wo, u0, u1, wi, fl);
+    if (pdf == 0.) return 0.;
+    wi_w = l2w(vx, wi);
+    if (n_match > 1) pdf /= n_match;
+    f = fl;
+    return pdf;
+}
+
+// ---------------------------------------------------------------------------------------
+// lights
+// ---------------------------------------------------------------------------------------
+// Transform.__call__ on Point (affine rows) / Vector / Normal, transform/__init__.py:54-69
+__device__ __forceinline__ d3 xf_point(const double *m, d3 p) {
+    return mk3((m[0] * p.x + m[1] * p.y + m[2] * p.z) + m[3], (m[4] * p.x + m[5] * p.y + m[6] * p.z) + m[7],
+               (m[8] * p.x + m[9] * p.y + m[10] * p.z) + m[11]);
+}
+__device__ __forceinline__ d3 xf_vec(const double *m, d3 v) {
+    return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+               m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+__device__ __forceinline__ d3 xf_normal(const double *minv, d3 n) {
+    return mk3(minv[0] * n.x + minv[4] * n.y + minv[8] * n.z, minv[1] * n.x + minv[5] * n.y + minv[9] * n.z,
+               minv[2] * n.x + minv[6] * n.y + minv[10] * n.z);
+}
+
+// geometry/utility.py:25-52
+__device__ inline void coordinate_system(d3 v1, d3 &v2, d3 &v3) {
+    if (len3(v1) == 0.) { v2 = mk3(0, 1, 0); v3 = mk3(0, 0, 1); return; }
+    if (fabs(v1.x) > fabs(v1.y)) {
+        double inv_len = 1. / sqrt(v1.x * v1.x + v1.z * v1.z);
+        v2 = mk3(-v1.z * inv_len, 0., v1.x * inv_len);
+    } else {
+        double inv_len = 1. / sqrt(v1.y * v1.y + v1.z * v1.z);
+        v2 = mk3(0., -v1.z * inv_len, v1.y * inv_len);
+    }
+    v3 = cross3(v1, v2);
+}
+
+// Sphere.intersect for a full sphere, shape/sphere.py:125-157 (np.roots → closed form)
+__device__ inline bool sphere_intersect(const pt_light &lt, const Ray &rw, double &thit, d3 &phit_obj) {
+    d3 o = xf_point(lt.w2o, rw.o), d = xf_vec(lt.w2o, rw.d);
+    double A = sqlen3(d);
+    double B = 2 * dot3(d, o);
+    double C = sqlen3(o) - lt.radius * lt.radius;
+    double D = B * B - 4. * A * C;
+    if (D <= 0. + PT_EPS) return false;
+    double rootD = sqrt(D);
+    double q = (B < 0.) ? -.5 * (B - rootD) : -.5 * (B + rootD);
+    double t0 = q / A, t1 = C / q;
+    if (t0 > t1) { double tmp = t0; t0 = t1; t1 = tmp; }
+    if (t0 > rw.maxt || t1 < rw.mint) return false;
+    double th = t0;
+    if (t0 < rw.mint) { th = t1; if (th > rw.maxt) return false; }
+    thit = th;
+    phit_obj = o + d * th;
+    return true;
+}
+
+// dg.nn of a full-sphere hit, sphere.py:186-224 + diffgeom.py:30-38
+__device__ inline d3 sphere_hit_normal(const pt_light &lt, d3 phit) {
+    const double phiMax = 2. * PT_PI, thetaMin = PT_PI, thetaMax = 0.;
+    if (phit.x == 0. && phit.y == 0.) phit.x = PT_EPS * lt.radius;
+    double theta = acos(clipd(phit.z / lt.radius, -1., 1.));
+    double delta_theta = thetaMax - thetaMin;
+    d3 dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0.);
+    double zrad = sqrt(phit.x * phit.x + phit.y * phit.y);
+    double inv_zrad = 1. / zrad;
+    double cphi = phit.x * inv_zrad, sphi = phit.y * inv_zrad;
+    d3 dpdv = mk3(phit.z * cphi, phit.z * sphi, -lt.radius * sin(theta)) * delta_theta;
+    d3 nn = normalize3(cross3(xf_vec(lt.o2w, dpdu), xf_vec(lt.o2w, dpdv)));
+    const double *m = lt.o2w;
+    double det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) +
+                 m[2] * (m[4] * m[9] - m[5] * m[8]);
+    if ((lt.ro != 0) != (det < 0.)) nn = nn * -1.;
+    return nn;
+}
+
+struct LightSample {
+    d3 Li, wi;
+    double pdf;
+    Ray shadow;
+};
+
+// DiffuseAreaLight.sample_l (light/light.py:514-521) → Sphere.sample_p (shape/sphere.py:78-110),
+// Sphere.pdf_p (:112-123), VisibilityTester.set_segment (light/utility.py:34-42)
+__device__ inline void sphere_light_sample_l(const pt_light &lt, d3 p, double pEps, double u1, double u2,
+                                             LightSample &o) {
+    d3 ctr = mk3(lt.pos[0], lt.pos[1], lt.pos[2]);
+    d3 wc = normalize3(ctr - p);
+    d3 wcx, wcy;
+    coordinate_system(wc, wcx, wcy);
+    d3 dcp = p - ctr;
+    double sqd = dcp.x * dcp.x + dcp.y * dcp.y + dcp.z * dcp.z;
+    bool inside = (sqd - lt.radius * lt.radius < PT_EPS);
+    d3 ps, ns;
+    double pdf;
+    if (inside) {
+        // Sphere.sample AS WRITTEN, sphere.py:43-60 (Q7)
+        const double phiMax = 2. * PT_PI, thetaMin = PT_PI, thetaMax = 0.;
+        double z = 1. - 2. * u1;
+        double r = sqrt(max0(1. - z * z));
+        double ph = 2. * PT_PI * u2;
+        d3 v = mk3(r * cos(ph), r * sin(ph), z);
+        double sth = acos(clipd(v.z, -1., 1.));
+        double phi = sth * phiMax * PT_INV_2PI;
+        double theta = thetaMin + sth * (thetaMax - thetaMin);
+        double s = sin(theta), c = cos(theta);
+        v = mk3(s * cos(phi), s * sin(phi), c) * lt.radius;
+        v.z = -lt.radius + v.z * (lt.radius - (-lt.radius));
+        ns = normalize3(xf_normal(lt.w2o, v));
+        if (lt.ro) ns = ns * -1.;
+        ps = xf_point(lt.o2w, v);
+    } else {
+        double st_max_sq = lt.radius * lt.radius / sqd;
+        double ct_max = sqrt(max0(1. - st_max_sq));
+        // uniform_sample_cone with a basis, montecarlo/utility.py:222-226
+        double ct = (1. - u1) * ct_max + u1 * 1.;
+        double st = sqrt(1. - ct * ct);
+        double phi = u2 * 2. * PT_PI;
+        d3 dir = ((wcx * (cos(phi) * st)) + (wcy * (sin(phi) * st))) + (wc * ct);
+        Ray r;
+        r.o = p; r.d = dir; r.mint = PT_EPS; r.maxt = __builtin_inf();
+        double thit;
+        d3 dummy;
+        if (!sphere_intersect(lt, r, thit, dummy)) thit = dot3(ctr - p, normalize3(r.d));
+        ps = r.o + r.d * thit;
+        ns = normalize3(ps - ctr);
+        if (lt.ro) ns = ns * -1.;
+    }
+    d3 wi = normalize3(ps - p);
+    if (inside) {
+        // Shape.pdf_p, shape/__init__.py:122-140
+        Ray r;
+        r.o = p; r.d = wi; r.mint = PT_EPS; r.maxt = __builtin_inf();
+        double thit;
+        d3 ph;
+        if (!sphere_intersect(lt, r, thit, ph)) pdf = 0.;
+        else {
+            d3 nn = sphere_hit_normal(lt, ph);
+            d3 hitp = r.o + r.d * thit;
+            double area = (2. * PT_PI) * lt.radius * (lt.radius - (-lt.radius));
+            pdf = sqlen3(p - hitp) / (fabs(dot3(nn, -wi)) * area);
+        }
+    } else {
+        double st_max_sq = lt.radius * lt.radius / sqd;
+        double ct_max = sqrt(max0(1. - st_max_sq));
+        pdf = 1. / (2. * PT_PI * (1. - ct_max));
+    }
+    // DiffuseAreaLight.l, light.py:507-508
+    if (dot3(ns, -wi) > 0.) o.Li = mk3(lt.emit[0], lt.emit[1], lt.emit[2]);
+    else o.Li = mk3(0, 0, 0);
+    o.wi = wi;
+    o.pdf = pdf;
+    double dist = len3(p - ps);
+    o.shadow.o = p;
+    o.shadow.d = (ps - p) / dist;
+    o.shadow.mint = pEps;
+    o.shadow.maxt = dist * (1. - PT_EPS);
+}
+
+// SpotLight.sample_l (light.py:190-196; divides by the falloff, no 1/r², Q9) and
+// PointLight.sample_l (light.py:129-135)
+__device__ inline void delta_light_sample_l(const pt_light &lt, d3 p, double pEps, LightSample &o) {
+    d3 pos = mk3(lt.pos[0], lt.pos[1], lt.pos[2]);
+    d3 wi = normalize3(pos - p);
+    d3 I = mk3(lt.emit[0], lt.emit[1], lt.emit[2]);
+    if (lt.kind == PT_LIGHT_SPOT) {
+        d3 wl = normalize3(xf_vec(lt.w2o, -wi));
+        double ct = wl.z, fo;
+        if (ct < lt.cos_width) fo = 0.;
+        else if (ct > lt.cos_falloff) fo = 1.;
+        else { double d = (ct - lt.cos_width) / (lt.cos_falloff - lt.cos_width); fo = d * d * d * d; }
+        o.Li = I / fo;
+    } else {
+        o.Li = I / sqlen3(pos - p);
+    }
+    o.wi = wi;
+    o.pdf = 1.;
+    double dist = len3(p - pos);
+    o.shadow.o = p;
+    o.shadow.d = (pos - p) / dist;
+    o.shadow.mint = pEps;
+    o.shadow.maxt = dist * (1. - 0.);
+}
+
+// util.is_black on an array: all |c| < EPS (utility/utility.py:119-124)
+__device__ __forceinline__ bool util_is_black(d3 s) { return fabs(s.x) < PT_EPS && fabs(s.y) < PT_EPS && fabs(s.z) < PT_EPS; }
+// CoefficientSpectrum.is_black: all c < EPS (spectral/spectrum.py:182-187)
+__device__ __forceinline__ bool spec_is_black(d3 s) { return s.x < PT_EPS && s.y < PT_EPS && s.z < PT_EPS; }
+// RGBSpectrum.y, spectrum.py:587-589
+__device__ __forceinline__ double spec_y(d3 s) { return (0.212671 * s.x + 0.715160 * s.y) + 0.072169 * s.z; }
+
+// ---------------------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lane_prefix(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// Append `pred` lanes of this wave to a queue: one atomic per wave (ballot + prefix sum).
+// Every lane of the wave must call it (convergent).  Returns the lane's position or -1.
+__device__ __forceinline__ int wave_append(bool pred, int *counter) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return -1;
+    unsigned n = (unsigned)__popcll(mask);
+    unsigned rank = lane_prefix(mask);
+    int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, (int)n);
+    base = __shfl(base, leader);
+    return pred ? base + (int)rank : -1;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}

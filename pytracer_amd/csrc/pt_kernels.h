@@ -1,0 +1,86 @@
+// pt_kernels.h — shared declarations of the kernels (pt_kernels.hip) and the C-ABI host
+// layer (pt_api.hip).
+#pragma once
+
+#include "pt_device.h"
+
+#define PT_BLOCK 256   // 4 waves of 64 lanes
+
+enum {
+    CNT_NODE_VISITS = 0,
+    CNT_TRI_TESTS,
+    CNT_RAYS_CLOSEST,
+    CNT_RAYS_ANY,
+    CNT_CAMERA_SAMPLES,
+    CNT_GUARD_NAN,
+    CNT_GUARD_NEG,
+    CNT_GUARD_INF,
+    CNT_COUNT
+};
+
+// dense ray queue: traced rays and (after K3) their hit records, plus the path slot they belong to
+struct Queue {
+    double *rays;   // [8][stride]: ox,oy,oz,dx,dy,dz,mint,maxt
+    long stride;
+    int *slot;      // [stride]
+    int *prim;      // [stride] closest-hit primitive or -1
+    double *t;      // [stride] ray.maxt after traversal
+    double *b1, *b2;
+    int *count;     // device counter
+};
+
+// dense shadow-ray queue with the contribution each ray carries if unoccluded
+struct ShadowQueue {
+    double *rays;   // [8][stride]
+    double *c;      // [3][stride]
+    long stride;
+    int *slot;
+    int *count;
+};
+
+struct ShadowResolve {
+    const double *c;
+    long cstride;
+    const int *slot;
+    double *L;
+    long lstride;
+};
+
+// per-path state, indexed by slot (= sample ordinal inside the batch)
+struct PathState {
+    double *T;     // [3][stride] path throughput
+    double *L;     // [3][stride] accumulated radiance
+    double *img;   // [2][stride] imageX, imageY
+    long stride;
+};
+
+// offsets into a flattened Sample row (sampler/sample.py:36-76): [imageX,imageY,lens_u,lens_v,time,
+// oneD arrays..., twoD arrays...] with the requests of direct.py:46-62 / path.py:34-42
+struct Layout {
+    int32_t dims;
+    int32_t d_lpos[16], d_ns[16];
+    int32_t p_lnum[3], p_lpos[3], p_pcom[3], p_pdir[3];
+};
+
+struct RenderConst {
+    pt_camera cam;
+    pt_film_desc film;
+    pt_sampler_desc sp;
+    pt_integrator_desc ig;
+    pt_tile tile;
+    Layout lay;
+    const double *table;
+};
+
+hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                           long stride, const int *n_ptr, int n_val, int *out_prim, double *out_t, double *out_b1,
+                           double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
+hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, const Queue &q,
+                            const PathState &st, unsigned long long *counters);
+hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,
+                           int level, const Queue &qin, const Queue &qout, const ShadowQueue &sh,
+                           const PathState &st);
+hipError_t pt_launch_splat(int grid, hipStream_t stream, const RenderConst *rc, int nb, const PathState &st,
+                           double *film, double *sample_L, long base_out, unsigned long long *counters);
+hipError_t pt_launch_film_resolve(hipStream_t stream, const double *acc, long npix, double *rgb);
+hipError_t pt_launch_set_int(hipStream_t stream, int *p, int v);

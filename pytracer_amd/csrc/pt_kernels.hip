@@ -1,0 +1,583 @@
+// pt_kernels.hip — wavefront kernels of the MI355X back end (gfx950, wave64).
+//
+// Stages (SURVEY.md §8(a')): K1 raygen → K3 trace_closest → K4 shade (+K5 light sampling)
+// → K2 trace_any (+K6 shadow resolve) → … → K7 film splat, K8 film resolve.
+// No MFMA anywhere: ray–box / ray–triangle tests and BSDF evaluation are not dense
+// contractions; the bounding resource is cache/HBM bandwidth and divergent fp64 VALU.
+#include "pt_kernels.h"
+
+// =========================================================================================
+// BVH traversal.  One lane per ray; the per-lane todo stack of bvh.py:332 lives in LDS as
+// stack[level][thread] so that lane l always hits bank l (conflict-free ds_read/write_b32).
+// =========================================================================================
+
+// Triangle.intersect / intersect_p up to the range test (shape/triangle.py:173-207,245-279)
+__device__ __forceinline__ bool tri_test(const GTri *tp, const Ray &r, double &t_out, double &b1_out, double &b2_out) {
+    const double2 *q = reinterpret_cast<const double2 *>(tp);
+    double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+    d3 p1 = mk3(a0.x, a0.y, a1.x), e1 = mk3(a1.y, a2.x, a2.y), e2 = mk3(a3.x, a3.y, a4.x);
+    d3 s1 = cross3(r.d, e2);
+    double div = dot3(s1, e1);
+    if (div == 0.0) return false;
+    double divInv = 1.0 / div;
+    d3 d = r.o - p1;
+    double b1 = dot3(d, s1) * divInv;
+    if (b1 < 0.0 || b1 > 1.0) return false;
+    d3 s2 = cross3(d, e1);
+    double b2 = dot3(r.d, s2) * divInv;
+    if (b2 < 0.0 || (b1 + b2) > 1.0) return false;
+    double t = dot3(e2, s2) * divInv;
+    if (t < r.mint || t > r.maxt) return false;
+    t_out = t; b1_out = b1; b2_out = b2;
+    return true;
+}
+
+// BVH.intersect (bvh.py:322-365) / BVH.intersect_p (:367-410) with BVH._intersect_p (:295-320).
+// Returns the primitive index (closest; -1 = miss) or 0/1 (any hit).  r.maxt is shrunk by
+// every accepted closest hit (aggregate/primitive.py:107).
+template <bool ANY>
+__device__ __forceinline__ int traverse(const DScene &sc, Ray &r, int *stack, double &b1o, double &b2o,
+                                        unsigned &nvis, unsigned &ntri) {
+    int result = ANY ? 0 : -1;
+    if (sc.n_nodes == 0) return result;
+    const double invx = 1.0 / r.d.x, invy = 1.0 / r.d.y, invz = 1.0 / r.d.z;
+    const bool negx = r.d.x < 0.0, negy = r.d.y < 0.0, negz = r.d.z < 0.0;
+    int todo_idx = 0, node_idx = 0;
+    for (;;) {
+        const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node_idx);
+        double2 n0 = q[0], n1 = q[1], n2 = q[2];   // bmin.xy | bmin.z bmax.x | bmax.yz
+        int2 meta = *reinterpret_cast<const int2 *>(&q[3]);
+        nvis++;
+        double tmin = ((negx ? n1.y : n0.x) - r.o.x) * invx;
+        double tmax = ((negx ? n0.x : n1.y) - r.o.x) * invx;
+        double tmin_y = ((negy ? n2.x : n0.y) - r.o.y) * invy;
+        double tmax_y = ((negy ? n0.y : n2.x) - r.o.y) * invy;
+        bool hitbox = !(tmin > tmax_y || tmin_y > tmax);
+        if (hitbox) {
+            if (tmin_y > tmin) tmin = tmin_y;
+            if (tmax_y < tmax) tmax = tmax_y;
+            double tmin_z = ((negz ? n2.y : n1.x) - r.o.z) * invz;
+            double tmax_z = ((negz ? n1.x : n2.y) - r.o.z) * invz;
+            hitbox = !(tmin > tmax_z || tmin_z > tmax);
+            if (hitbox) {
+                if (tmin_z > tmin) tmin = tmin_z;
+                if (tmax_z < tmax) tmax = tmax_z;
+                hitbox = (tmin < r.maxt) && (tmax > r.mint);
+            }
+        }
+        if (hitbox) {
+            const int nprim = meta.y & 0xFFFF;
+            if (nprim > 0) {
+                for (int i = 0; i < nprim; i++) {
+                    double t, b1, b2;
+                    ntri++;
+                    if (tri_test(sc.tris + meta.x + i, r, t, b1, b2)) {
+                        if (ANY) return 1;
+                        result = meta.x + i;
+                        b1o = b1; b2o = b2;
+                        r.maxt = t;
+                    }
+                }
+                if (todo_idx == 0) break;
+                node_idx = stack[(--todo_idx) * PT_BLOCK];
+            } else {
+                const int axis = meta.y >> 16;
+                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
+                stack[(todo_idx++) * PT_BLOCK] = neg ? node_idx + 1 : meta.x;
+                node_idx = neg ? meta.x : node_idx + 1;
+            }
+        } else {
+            if (todo_idx == 0) break;
+            node_idx = stack[(--todo_idx) * PT_BLOCK];
+        }
+    }
+    return result;
+}
+
+// rays: component-major SoA [8][stride]; outputs dense per ray.  ANY + rs.L: the shadow
+// "resolve" (K6) is fused: an unoccluded ray adds its precomputed contribution to L[slot].
+template <int STACK, bool ANY>
+__global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene sc, const double *__restrict__ rays, long stride,
+                                                    const int *__restrict__ n_ptr, int n_val,
+                                                    int *__restrict__ out_prim, double *__restrict__ out_t,
+                                                    double *__restrict__ out_b1, double *__restrict__ out_b2,
+                                                    ShadowResolve rs, unsigned long long *counters) {
+    __shared__ int s_stack[STACK * PT_BLOCK];
+    const int n = n_ptr ? *n_ptr : n_val;
+    unsigned nvis = 0, ntri = 0, nray = 0;
+    for (long i = (long)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * PT_BLOCK) {
+        Ray r;
+        r.o = mk3(rays[i], rays[stride + i], rays[2 * stride + i]);
+        r.d = mk3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
+        r.mint = rays[6 * stride + i];
+        r.maxt = rays[7 * stride + i];
+        double b1 = 0., b2 = 0.;
+        int res = traverse<ANY>(sc, r, s_stack + threadIdx.x, b1, b2, nvis, ntri);
+        nray++;
+        if (out_prim) out_prim[i] = res;
+        if (!ANY) {
+            if (out_t) out_t[i] = r.maxt;
+            if (out_b1) out_b1[i] = b1;
+            if (out_b2) out_b2[i] = b2;
+        } else if (rs.L && res == 0) {
+            const int slot = rs.slot[i];
+            unsafeAtomicAdd(rs.L + slot, rs.c[i]);
+            unsafeAtomicAdd(rs.L + rs.lstride + slot, rs.c[rs.cstride + i]);
+            unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + i]);
+        }
+    }
+    if (counters) {
+        unsigned long long v = wave_sum_u64(nvis), w = wave_sum_u64(ntri), x = wave_sum_u64(nray);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(counters + CNT_NODE_VISITS, v);
+            atomicAdd(counters + CNT_TRI_TESTS, w);
+            atomicAdd(counters + (ANY ? CNT_RAYS_ANY : CNT_RAYS_CLOSEST), x);
+        }
+    }
+}
+
+template <bool ANY>
+static hipError_t launch_trace_t(int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                                 long stride, const int *n_ptr, int n_val, int *out_prim, double *out_t,
+                                 double *out_b1, double *out_b2, const ShadowResolve &rs,
+                                 unsigned long long *counters) {
+#define PT_LAUNCH(S)                                                                                      \
+    hipLaunchKernelGGL((k_trace<S, ANY>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays, stride, n_ptr, \
+                       n_val, out_prim, out_t, out_b1, out_b2, rs, counters)
+    if (stack <= 16) PT_LAUNCH(16);
+    else if (stack <= 24) PT_LAUNCH(24);
+    else if (stack <= 32) PT_LAUNCH(32);
+    else if (stack <= 48) PT_LAUNCH(48);
+    else PT_LAUNCH(64);
+#undef PT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                           long stride, const int *n_ptr, int n_val, int *out_prim, double *out_t, double *out_b1,
+                           double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
+    if (any) return launch_trace_t<true>(stack, grid, stream, sc, rays, stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    return launch_trace_t<false>(stack, grid, stream, sc, rays, stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+}
+
+// =========================================================================================
+// sample streams
+// =========================================================================================
+
+// Fisher–Yates on a nibble-packed permutation of n <= 16 (DESIGN.md "sample streams")
+__device__ inline unsigned long long lhs_perm(int n, uint32_t sid, uint32_t key) {
+    unsigned long long p = 0xFEDCBA9876543210ull;
+    for (int i = n - 1; i > 0; i--) {
+        int j = (int)floor(hash_uniform(sid, key + (uint32_t)i) * (i + 1));
+        if (j > i) j = i;
+        unsigned long long a = (p >> (4 * i)) & 15ull, b = (p >> (4 * j)) & 15ull;
+        p &= ~((15ull << (4 * i)) | (15ull << (4 * j)));
+        p |= (b << (4 * i)) | (a << (4 * j));
+    }
+    return p;
+}
+
+struct SampleSrc {
+    const double *row;   // parity: table row; production: nullptr
+    uint32_t msid;       // seed-mixed sample ordinal (production) / raw ordinal (parity rng)
+};
+
+// value of flattened sample dimension k >= 5 for the PATH layout (all arrays have n = 1)
+__device__ __forceinline__ double path_dim(const SampleSrc &s, int k) {
+    return s.row ? s.row[k] : hash_uniform(s.msid, 0x10000u + (uint32_t)k);
+}
+
+// LightSample.u_pos of sample j of a Direct-lighting 2D array of n entries starting at `off`
+// (latin_hypercube_2d, sampler/utility.py:41-44: x stratum = j, y stratum = shuffled)
+__device__ inline void direct_light_uv(const SampleSrc &s, int off, int n, int j, unsigned long long perm,
+                                       double &u0, double &u1) {
+    if (s.row) { u0 = s.row[off + 2 * j]; u1 = s.row[off + 2 * j + 1]; return; }
+    u0 = (j + hash_uniform(s.msid, 0x10000u + (uint32_t)(off + 2 * j))) / n;
+    u1 = ((int)((perm >> (4 * j)) & 15ull) + hash_uniform(s.msid, 0x10000u + (uint32_t)(off + 2 * j + 1))) / n;
+}
+
+__device__ __forceinline__ void tile_decode(const RenderConst &rc, long out_i, int &px, int &py, int &si, uint32_t &sid) {
+    const int ns = rc.tile.s1 - rc.tile.s0, tw = rc.tile.x1 - rc.tile.x0;
+    long pix = out_i / ns;
+    si = rc.tile.s0 + (int)(out_i - pix * ns);
+    py = rc.tile.y0 + (int)(pix / tw);
+    px = rc.tile.x0 + (int)(pix - (long)(py - rc.tile.y0) * tw);
+    const int spp = rc.sp.xs * rc.sp.ys, W = rc.sp.x_end - rc.sp.x_start;
+    sid = (uint32_t)((((long)(py - rc.sp.y_start) * W + (px - rc.sp.x_start)) * spp) + si);
+}
+
+__device__ __forceinline__ SampleSrc sample_src(const RenderConst &rc, uint32_t sid) {
+    SampleSrc s;
+    s.row = rc.table ? rc.table + (size_t)sid * rc.lay.dims : nullptr;
+    s.msid = rc.table ? sid : mix_seed(sid, rc.sp.seed);
+    return s;
+}
+
+// =========================================================================================
+// K1 raygen: StratifiedSampler.generate (sampler/sampler/stratified.py:45-89) +
+// PerspectiveCamera.generate_ray_differential (camera/projective.py:178-232; o and d only —
+// ray differentials feed textures and every supported texture is constant).
+// =========================================================================================
+__device__ __forceinline__ bool ne_unity(double x) { return x < 1. - PT_EPS || x > 1. + PT_EPS; }
+// Transform.__call__ on a Point with the perspective divide, transform/__init__.py:55-60
+__device__ inline d3 xf4_point(const double *m, d3 p) {
+    double r0 = (m[0] * p.x + m[1] * p.y + m[2] * p.z) + m[3];
+    double r1 = (m[4] * p.x + m[5] * p.y + m[6] * p.z) + m[7];
+    double r2 = (m[8] * p.x + m[9] * p.y + m[10] * p.z) + m[11];
+    double r3 = (m[12] * p.x + m[13] * p.y + m[14] * p.z) + m[15];
+    d3 r = mk3(r0, r1, r2);
+    if (ne_unity(r3)) r = r / r3;
+    return r;
+}
+// concentric_sample_disk, montecarlo/utility.py:122-168
+__device__ inline void concentric_sample_disk(double u1, double u2, double &ox, double &oy) {
+    double sx = 2. * u1 - 1., sy = 2. * u2 - 1., r, theta;
+    if (sx == 0. && sy == 0.) { ox = 0.; oy = 0.; return; }
+    if (sx > -sy) {
+        if (sx > sy) { r = sx; theta = sy / sx; if (sy <= 0.) theta += 8.; }
+        else { r = sy; theta = 2. - sx / sy; }
+    } else {
+        if (sx > sy) { r = -sy; theta = 6. + sx / sy; }
+        else { r = -sx; theta = 4. - sy / sx; }
+    }
+    theta *= PT_PI / 4.;
+    ox = r * cos(theta); oy = r * sin(theta);
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restrict__ rcp, long base, int nb,
+                                                     Queue q, PathState st, unsigned long long *counters) {
+    const RenderConst &rc = *rcp;
+    const int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= nb) return;
+    int px, py, si;
+    uint32_t sid;
+    tile_decode(rc, base + i, px, py, si, sid);
+    SampleSrc ss = sample_src(rc, sid);
+    double ix, iy, lu, lv;
+    if (ss.row) { ix = ss.row[0]; iy = ss.row[1]; lu = ss.row[2]; lv = ss.row[3]; }
+    else {
+        const int sx = si % rc.sp.xs, sy = si / rc.sp.xs;
+        double jx = rc.sp.jitter ? hash_uniform(ss.msid, 0x10000u + 0) : .5;
+        double jy = rc.sp.jitter ? hash_uniform(ss.msid, 0x10000u + 1) : .5;
+        ix = (sx + jx) / rc.sp.xs + px;
+        iy = (sy + jy) / rc.sp.ys + py;
+        lu = hash_uniform(ss.msid, 0x10000u + 2);
+        lv = hash_uniform(ss.msid, 0x10000u + 3);
+    }
+    d3 p_cam = xf4_point(rc.cam.r2c, mk3(ix, iy, 0.));
+    d3 o = mk3(0, 0, 0);
+    d3 d = normalize3(p_cam);
+    if (rc.cam.lens_rad > 0.) {
+        double a, b;
+        concentric_sample_disk(lu, lv, a, b);
+        a *= rc.cam.lens_rad; b *= rc.cam.lens_rad;
+        double ft = rc.cam.focal_dist / d.z;
+        d3 Pfoc = o + d * ft;
+        o = mk3(a, b, 0.);
+        d = normalize3(Pfoc - o);
+    }
+    o = xf4_point(rc.cam.c2w, o);
+    d = xf_vec(rc.cam.c2w, d);
+    const long S = q.stride;
+    q.rays[i] = o.x; q.rays[S + i] = o.y; q.rays[2 * S + i] = o.z;
+    q.rays[3 * S + i] = d.x; q.rays[4 * S + i] = d.y; q.rays[5 * S + i] = d.z;
+    q.rays[6 * S + i] = 0.; q.rays[7 * S + i] = __builtin_inf();
+    q.slot[i] = i;
+    const long P = st.stride;
+    st.T[i] = 1.; st.T[P + i] = 1.; st.T[2 * P + i] = 1.;
+    st.L[i] = 0.; st.L[P + i] = 0.; st.L[2 * P + i] = 0.;
+    st.img[i] = ix; st.img[P + i] = iy;
+    if (counters && threadIdx.x == 0) {
+        int cnt = nb - blockIdx.x * PT_BLOCK;
+        atomicAdd(counters + CNT_CAMERA_SAMPLES, (unsigned long long)(cnt > PT_BLOCK ? PT_BLOCK : cnt));
+    }
+}
+
+// =========================================================================================
+// K4 shade (+K5 light sampling).  One lane per entry of the input queue (a traced ray and
+// its hit record).  Emits shadow rays with their pre-weighted contribution, and at most one
+// continuation ray; both queues are built with wave ballot + prefix sum (one atomic/wave).
+// =========================================================================================
+
+// estimate_direct AS IT EXECUTES (integrator/utility.py:203-257; only the light-sampling half
+// contributes, Q3).  Returns true if a shadow ray must be traced; c = contribution if unoccluded.
+__device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, const Vertex &vx, d3 wo, double u0,
+                                       double u1, Ray &shadow, d3 &c) {
+    const unsigned flags = BDF_ALL & ~BDF_SPECULAR;
+    LightSample ls;
+    if (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) sphere_light_sample_l(lt, vx.p, vx.rEps, u0, u1, ls);
+    else delta_light_sample_l(lt, vx.p, vx.rEps, ls);
+    if (!(ls.pdf > 0. && !util_is_black(ls.Li))) return false;
+    d3 f = bsdf_f(vx, wo, ls.wi, flags);
+    if (util_is_black(f)) return false;
+    double adot = fabs(dot3(ls.wi, vx.nn));
+    if (lt.kind != PT_LIGHT_DIFFUSE_SPHERE) {
+        c = (f * ls.Li) * (adot / ls.pdf);
+    } else {
+        double bp = bsdf_pdf(vx, wo, ls.wi, flags);
+        double ff = 1 * ls.pdf, g = 1 * bp;
+        double weight = ff * ff / (ff * ff + g * g);   // power_heuristic, montecarlo/utility.py:33-42
+        c = (f * ls.Li) * (adot * weight / ls.pdf);
+    }
+    shadow = ls.shadow;
+    return true;
+}
+
+__device__ __forceinline__ void push_shadow(const ShadowQueue &sh, bool pred, const Ray &r, d3 c, int slot) {
+    int pos = wave_append(pred, sh.count);
+    if (pos >= 0) {
+        const long S = sh.stride;
+        sh.rays[pos] = r.o.x; sh.rays[S + pos] = r.o.y; sh.rays[2 * S + pos] = r.o.z;
+        sh.rays[3 * S + pos] = r.d.x; sh.rays[4 * S + pos] = r.d.y; sh.rays[5 * S + pos] = r.d.z;
+        sh.rays[6 * S + pos] = r.mint; sh.rays[7 * S + pos] = r.maxt;
+        sh.c[pos] = c.x; sh.c[S + pos] = c.y; sh.c[2 * S + pos] = c.z;
+        sh.slot[pos] = slot;
+    }
+}
+
+// KIND 0: DirectLightingIntegrator.li (integrator/surface/direct.py:70-105) as a loop over the
+//   specular-reflection chain (specular_transmit contributes exactly 0, Q5, and is not traced;
+//   specular_reflect, integrator/utility.py:120-155, recurses through renderer.li, which adds
+//   Σ light.le on a miss, renderer/renderer.py:58-75).  `level` = ray.depth.
+// KIND 1: PathIntegrator.li AS IT EXECUTES (integrator/surface/path.py:44-144; `specular_bounce`
+//   always True after the first sample_f, Q4).  `level` = bounce_cnt.
+template <int KIND>
+__global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
+                                                    int level, Queue qin, Queue qout, ShadowQueue sh, PathState st) {
+    const RenderConst &rc = *rcp;
+    const int n = *qin.count;
+    const int nloop = (n + 63) & ~63;   // whole waves stay convergent for the ballots
+    for (int i = blockIdx.x * PT_BLOCK + threadIdx.x; i < nloop; i += gridDim.x * PT_BLOCK) {
+        const bool live = i < n;
+        int slot = 0, prim = -1;
+        if (live) { slot = qin.slot[i]; prim = qin.prim[i]; }
+        const long P = st.stride, S = qin.stride;
+        d3 T = mk3(0, 0, 0);
+        if (live) T = mk3(st.T[slot], st.T[P + slot], st.T[2 * P + slot]);
+        if (live && prim < 0 && level > 0) {
+            // escaped continuation ray: Σ light.le(ray) (renderer.py:66-68 / path.py:130-135)
+            st.L[slot] += T.x * sc.le_sum[0];
+            st.L[P + slot] += T.y * sc.le_sum[1];
+            st.L[2 * P + slot] += T.z * sc.le_sum[2];
+        }
+        const bool hit = live && prim >= 0;
+        Ray ray;
+        Vertex vx;
+        d3 wo = mk3(0, 0, 0);
+        SampleSrc ss;
+        ss.row = nullptr; ss.msid = 0;
+        if (hit) {
+            ray.o = mk3(qin.rays[i], qin.rays[S + i], qin.rays[2 * S + i]);
+            ray.d = mk3(qin.rays[3 * S + i], qin.rays[4 * S + i], qin.rays[5 * S + i]);
+            make_vertex(sc, ray, prim, qin.t[i], vx);
+            wo = -ray.d;
+            int px, py, si;
+            uint32_t sid;
+            tile_decode(rc, base + slot, px, py, si, sid);
+            ss = sample_src(rc, sid);
+        }
+        bool cont = false;
+        Ray nray;
+        if (KIND == PT_INTEG_DIRECT) {
+            // uniform_sample_all_lights, integrator/utility.py:45-77
+            for (int li = 0; li < sc.n_lights; li++) {
+                const int ns = rc.lay.d_ns[li], off = rc.lay.d_lpos[li];
+                unsigned long long perm = 0;
+                if (hit && !ss.row) perm = lhs_perm(ns, ss.msid, 0x20000u + (uint32_t)off * 64u);
+                for (int j = 0; j < ns; j++) {
+                    bool need = false;
+                    Ray sr;
+                    d3 c = mk3(0, 0, 0);
+                    if (hit) {
+                        double u0, u1;
+                        direct_light_uv(ss, off, ns, j, perm, u0, u1);
+                        need = estimate_direct(sc, sc.lights[li], vx, wo, u0, u1, sr, c);
+                        c = T * (c / (double)ns);
+                    }
+                    push_shadow(sh, need, sr, c, slot);
+                }
+            }
+            if (hit && (level + 1 < rc.ig.max_depth)) {
+                d3 wi, f;
+                double pdf = bsdf_sample_f(vx, wo, 0., 0., 0., BDF_REFLECTION | BDF_SPECULAR, wi, f);
+                double adot = fabs(dot3(wi, vx.nn));
+                if (pdf > 0. && !util_is_black(f) && adot != 0.) {
+                    T = T * ((f * adot) / pdf);
+                    cont = true;
+                    nray.o = vx.p; nray.d = wi; nray.mint = vx.rEps; nray.maxt = __builtin_inf();
+                }
+            }
+        } else {
+            bool need = false;
+            Ray sr;
+            d3 c = mk3(0, 0, 0);
+            // rng() draw counter (path.py:105,119; integrator/utility.py:101,113-114): per bounce >= 3,
+            // 7 draws in uniform_sample_one_light (if any light), 3 for the path BSDFSample, 1 for the
+            // roulette once bounce_cnt > 3
+            const uint32_t nl = sc.n_lights > 0 ? 7u : 0u;
+            uint32_t k = 0;
+            if (level >= 4) k = (nl + 3u) + (nl + 4u) * (uint32_t)(level - 4);
+            if (hit && sc.n_lights > 0) {
+                // uniform_sample_one_light, integrator/utility.py:80-117
+                double ulnum, u0, u1;
+                if (level < 3) {
+                    ulnum = path_dim(ss, rc.lay.p_lnum[level]);
+                    u0 = path_dim(ss, rc.lay.p_lpos[level]);
+                    u1 = path_dim(ss, rc.lay.p_lpos[level] + 1);
+                } else {
+                    ulnum = hash_uniform(ss.msid, k);
+                    u0 = hash_uniform(ss.msid, k + 1);
+                    u1 = hash_uniform(ss.msid, k + 2);
+                }
+                int ln = (int)floor(ulnum * sc.n_lights);
+                if (ln > sc.n_lights - 1) ln = sc.n_lights - 1;
+                need = estimate_direct(sc, sc.lights[ln], vx, wo, u0, u1, sr, c);
+                c = T * (c * (double)sc.n_lights);
+            }
+            push_shadow(sh, need, sr, c, slot);
+            if (hit) {
+                double u0, u1, uc;
+                if (level < 3) {
+                    u0 = path_dim(ss, rc.lay.p_pdir[level]);
+                    u1 = path_dim(ss, rc.lay.p_pdir[level] + 1);
+                    uc = path_dim(ss, rc.lay.p_pcom[level]);
+                } else {
+                    const uint32_t kk = k + nl;
+                    u0 = hash_uniform(ss.msid, kk);
+                    u1 = hash_uniform(ss.msid, kk + 1);
+                    uc = hash_uniform(ss.msid, kk + 2);
+                }
+                d3 wi, f;
+                double pdf = bsdf_sample_f(vx, wo, u0, u1, uc, BDF_ALL, wi, f);
+                if (!(spec_is_black(f) || pdf == 0.)) {
+                    T = T * ((f * fabs(dot3(wi, vx.nn))) / pdf);
+                    cont = true;
+                    if (level > 3) {
+                        double ty = spec_y(T);
+                        double cont_prob = ty < .5 ? ty : .5;
+                        const uint32_t kr = k + nl + 3u;
+                        if (hash_uniform(ss.msid, kr) > cont_prob) cont = false;
+                        T = T / cont_prob;
+                    }
+                    if (level == rc.ig.max_depth) cont = false;
+                    nray.o = vx.p; nray.d = wi; nray.mint = vx.rEps; nray.maxt = __builtin_inf();
+                }
+            }
+        }
+        int pos = wave_append(cont, qout.count);
+        if (pos >= 0) {
+            const long SO = qout.stride;
+            qout.rays[pos] = nray.o.x; qout.rays[SO + pos] = nray.o.y; qout.rays[2 * SO + pos] = nray.o.z;
+            qout.rays[3 * SO + pos] = nray.d.x; qout.rays[4 * SO + pos] = nray.d.y; qout.rays[5 * SO + pos] = nray.d.z;
+            qout.rays[6 * SO + pos] = nray.mint; qout.rays[7 * SO + pos] = nray.maxt;
+            qout.slot[pos] = slot;
+            st.T[slot] = T.x; st.T[P + slot] = T.y; st.T[2 * P + slot] = T.z;
+        }
+    }
+}
+
+hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, const Queue &q,
+                            const PathState &st, unsigned long long *counters) {
+    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(PT_BLOCK), 0, stream, rc, base, nb, q, st, counters);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,
+                           int level, const Queue &qin, const Queue &qout, const ShadowQueue &sh,
+                           const PathState &st) {
+    if (kind == PT_INTEG_DIRECT)
+        hipLaunchKernelGGL((k_shade<PT_INTEG_DIRECT>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, qout, sh, st);
+    else
+        hipLaunchKernelGGL((k_shade<PT_INTEG_PATH>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, qout, sh, st);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// K7 film splat: the radiance guards of SamplerRendererTask.__call__ (renderer/renderer.py:
+// 185-193) + ImageFilm.add_sample (film/film.py:137-198).  film_accum[y][x][4] f64.
+// =========================================================================================
+__global__ __launch_bounds__(PT_BLOCK) void k_splat(const RenderConst *__restrict__ rcp, int nb, PathState st,
+                                                    double *__restrict__ film, double *__restrict__ sample_L,
+                                                    long base_out, unsigned long long *counters) {
+    const RenderConst &rc = *rcp;
+    const int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= nb) return;
+    const long P = st.stride;
+    d3 L = mk3(st.L[i], st.L[P + i], st.L[2 * P + i]);
+    if (isnan(L.x) || isnan(L.y) || isnan(L.z)) {
+        L = mk3(0, 0, 0);
+        if (counters) atomicAdd(counters + CNT_GUARD_NAN, 1ull);
+    } else if (spec_y(L) < -PT_EPS) {
+        L = mk3(0, 0, 0);
+        if (counters) atomicAdd(counters + CNT_GUARD_NEG, 1ull);
+    } else if (spec_y(L) == __builtin_inf()) {
+        L = mk3(0, 0, 0);
+        if (counters) atomicAdd(counters + CNT_GUARD_INF, 1ull);
+    }
+    if (sample_L) {
+        sample_L[3 * (base_out + i)] = L.x;
+        sample_L[3 * (base_out + i) + 1] = L.y;
+        sample_L[3 * (base_out + i) + 2] = L.z;
+    }
+    if (!film) return;
+    const pt_film_desc &fm = rc.film;
+    const double dX = st.img[i] - .5, dY = st.img[P + i] - .5;
+    int x0 = (int)ceil(dX - fm.xw), x1 = (int)floor(dX + fm.xw);
+    int y0 = (int)ceil(dY - fm.yw), y1 = (int)floor(dY + fm.yw);
+    x0 = max(x0, fm.x_start); x1 = min(x1, fm.x_start + fm.x_cnt - 1);
+    y0 = max(y0, fm.y_start); y1 = min(y1, fm.y_start + fm.y_cnt - 1);
+    if (x1 - x0 < 0 || y1 - y0 < 0) return;
+    // rgb2xyz, spectral/spectrum.py:31-34
+    const double X = (0.412453 * L.x + 0.357580 * L.y) + 0.180423 * L.z;
+    const double Y = (0.212671 * L.x + 0.715160 * L.y) + 0.072169 * L.z;
+    const double Z = (0.019334 * L.x + 0.119193 * L.y) + 0.950227 * L.z;
+    const double xwInv = 1. / fm.xw, ywInv = 1. / fm.yw;
+    for (int y = y0; y <= y1; y++) {
+        int ify = (int)floor(fabs((y - dY) * 16 * ywInv));
+        ify = min(ify, 15);
+        for (int x = x0; x <= x1; x++) {
+            int ifx = (int)floor(fabs((x - dX) * 16 * xwInv));
+            ifx = min(ifx, 15);
+            const double wt = rc.film.table[ify * 16 + ifx];
+            double *px = film + 4 * ((size_t)(y - fm.y_start) * fm.x_cnt + (x - fm.x_start));
+            unsafeAtomicAdd(px + 0, wt * X);
+            unsafeAtomicAdd(px + 1, wt * Y);
+            unsafeAtomicAdd(px + 2, wt * Z);
+            unsafeAtomicAdd(px + 3, wt);
+        }
+    }
+}
+
+hipError_t pt_launch_splat(int grid, hipStream_t stream, const RenderConst *rc, int nb, const PathState &st,
+                           double *film, double *sample_L, long base_out, unsigned long long *counters) {
+    hipLaunchKernelGGL(k_splat, dim3(grid), dim3(PT_BLOCK), 0, stream, rc, nb, st, film, sample_L, base_out, counters);
+    return hipGetLastError();
+}
+
+// K8 film resolve: ImageFilm.write_image pixel loop, film/film.py:243-256 (xyz2rgb spectrum.py:25-28)
+__global__ __launch_bounds__(PT_BLOCK) void k_film_resolve(const double *__restrict__ acc, long npix,
+                                                           double *__restrict__ rgb) {
+    const long i = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= npix) return;
+    const double a0 = acc[4 * i], a1 = acc[4 * i + 1], a2 = acc[4 * i + 2], ws = acc[4 * i + 3];
+    double r = (3.240479 * a0 - 1.537150 * a1) - 0.498535 * a2;
+    double g = (-0.969256 * a0 + 1.875991 * a1) + 0.041556 * a2;
+    double b = (0.055648 * a0 - 0.204043 * a1) + 1.057311 * a2;
+    if (!(ws == 0.)) {
+        r = r / ws; g = g / ws; b = b / ws;
+        r = r > 0. ? r : 0.; g = g > 0. ? g : 0.; b = b > 0. ? b : 0.;
+    }
+    rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = b;
+}
+
+hipError_t pt_launch_film_resolve(hipStream_t stream, const double *acc, long npix, double *rgb) {
+    const int grid = (int)((npix + PT_BLOCK - 1) / PT_BLOCK);
+    if (grid > 0) hipLaunchKernelGGL(k_film_resolve, dim3(grid), dim3(PT_BLOCK), 0, stream, acc, npix, rgb);
+    return hipGetLastError();
+}
+
+__global__ void k_set_int(int *p, int v) { *p = v; }
+hipError_t pt_launch_set_int(hipStream_t stream, int *p, int v) {
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, stream, p, v);
+    return hipGetLastError();
+}
