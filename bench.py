@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): head mesh (2 778
+triangles, 5 537 BVH nodes; tests/golden/head_mesh_scene.npz, a dump of the reference's own
+examples/head_mesh.py scene), 1024x1024, 8x8 = 64 spp stratified, PathIntegrator max_depth 5,
+Lanczos(4,4,3) film.  One "step" = one full render: sample generation → camera rays → BVH
+closest/any hit → shading/light sampling → film splat (+ RCCL reduce of the film for N > 1)
+→ film resolve.  Inputs (scene, descriptors) are resident in HBM before the timed region.
+
+Multi-GPU: replicated scene, every rank renders all pixels with its own 64-spp sample stream
+(seed = rank), i.e. per-GPU work is fixed ("weak" scaling: N GPUs give a 64·N spp image in the
+same time); the only collective is the reduce of the film accumulators to rank 0.
+
+Prints ONE JSON line on rank 0 (see the driver contract); extra keys: `roofline` for the
+dominant kernel and `cpu_baseline` (the CPU oracle timed on this box's host, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(n_rays, n_nodes, n_tris):
+    """B_ray = 32·N_node + 36·N_tri + 48 (32 B node, 36 B triangle, 48 B ray+hit)."""
+    return 32.0 * n_nodes + 36.0 * n_tris + 48.0 * n_rays
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--res', type=int, default=1024)
+    ap.add_argument('--spp', type=int, default=8, help='strata per axis (spp = spp^2)')
+    ap.add_argument('--integrator', choices=['path', 'direct'], default='path')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(flat, cam, film, integ, res, xs):
+    """The oracle (CPU restatement, 1 thread) on a bounded window of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import oracle_lib as O
+    import pytracer_amd as pa
+    from pytracer_amd import _abi as A
+    osc = O.OracleScene(flat)
+    win = 160                                   # 160x160 pixels x 64 spp ≈ 1.6 M camera samples
+    x0 = (res - win) // 2
+    smp = pa.sampler_desc(0, res, 0, res, xs, xs, True, 0)
+    tile = pa.tile_desc(x0, x0 + win, x0, x0 + win, 0, xs * xs)
+    st = A.pt_stats()
+    t0 = time.perf_counter()
+    osc.render(cam, film, smp, integ, tile, stats=st, want_L=False)
+    dt = time.perf_counter() - t0
+    rays = st.rays_closest + st.rays_any
+    return {'value': rays / dt / 1e6, 'unit': 'Mrays/s', 'cores': 1, 'kind': 'port',
+            'samples_per_s': st.camera_samples / dt,
+            'sample': 'oracle/pt_oracle.c (1 thread), %dx%d-pixel centre window of the same %dx%d x %d spp render: '
+                      '%d camera samples, %d rays in %.1f s' % (win, win, res, res, xs * xs, st.camera_samples, rays, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import pytracer_amd as pa
+    from pytracer_amd import _abi as A
+    from pytracer_amd import host
+    from pytracer_amd._lib import Context
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local if world > 1 else 0)
+
+    d = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'head_mesh_scene.npz')))
+    flat = pa.flat_scene_from_npz(d)
+    ctx = Context(dev.index)
+    ctx.upload(flat)
+    ctx.set_profiling(True)
+    res, xs = args.res, args.spp
+    cam, film = host.head_mesh_camera_film(res, res)
+    kind = A.PT_INTEG_PATH if args.integrator == 'path' else A.PT_INTEG_DIRECT
+    integ = pa.integrator_desc(kind, 5, pretest=False)
+    smp = pa.sampler_desc(0, res, 0, res, xs, xs, True, seed=rank)
+    tile = pa.tile_desc(0, res, 0, res, 0, xs * xs)
+    acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(stats):
+        acc.zero_()
+        ctx.render(cam, film, smp, integ, tile, acc, stats=stats)
+        if dist is not None:
+            dist.reduce(acc, dst=0)             # RCCL sum of film accumulators over xGMI
+        return ctx.film_resolve(acc)
+
+    for _ in range(args.warmup):
+        step(A.pt_stats())
+    barrier()
+    st = A.pt_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rgb = step(st)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        cnt = torch.tensor([st.rays_closest + st.rays_any, st.camera_samples], dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt)
+        rays_total, samples_total = float(cnt[0].item()), float(cnt[1].item())
+    else:
+        rays_total, samples_total = float(st.rays_closest + st.rays_any), float(st.camera_samples)
+
+    if rank == 0:
+        # dominant kernel: whichever of the two traversal kernels took more time
+        n_any, n_clo = st.rays_any, st.rays_closest
+        nv_any, nt_any = st.node_visits_any, st.tri_tests_any
+        nv_clo, nt_clo = st.node_visits - nv_any, st.tri_tests - nt_any
+        cand = {
+            'k_trace<closest>': (st.ms_trace_closest, st.launches_trace_closest, algorithmic_bytes(n_clo, nv_clo, nt_clo),
+                                 n_clo, nv_clo, nt_clo),
+            'k_trace<any>': (st.ms_trace_any, st.launches_trace_any, algorithmic_bytes(n_any, nv_any, nt_any),
+                             n_any, nv_any, nt_any),
+        }
+        name = max(cand, key=lambda k: cand[k][0])
+        ms, launches, abytes, nr, nv, nt = cand[name]
+        achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': name,
+                'launches': int(launches), 'avg_launch_ms': ms / max(launches, 1),
+                'algorithmic_bytes_per_launch': abytes / max(launches, 1),
+                'rays': int(nr), 'node_visits_per_ray': nv / max(nr, 1), 'tri_tests_per_ray': nt / max(nr, 1),
+                'kernel_Mrays_per_s': nr / (ms * 1e-3) / 1e6 if ms > 0 else 0.0,
+                'stage_ms_per_step': {k: v / args.steps for k, v in st.timing().items()}}
+        out = {
+            'metric': 'Mrays/s', 'value': rays_total / dt / 1e6, 'unit': 'Mrays/s',
+            'samples_per_s': samples_total / dt,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'head_mesh %dx%d, %d spp stratified, %s max_depth 5, Lanczos(4,4,3) film '
+                                   '(BASELINE.json configs[2])' % (res, res, xs * xs,
+                                                                    'PathIntegrator' if kind else 'DirectLightingIntegrator'),
+                       'triangles': flat.n_tris, 'bvh_nodes': flat.n_nodes,
+                       'rays_per_sample': rays_total / max(samples_total, 1),
+                       'parallelism': 'replicated scene, per-rank sample streams, RCCL film reduce'
+                       if world > 1 else 'single GPU',
+                       'image_checksum': float(rgb.sum().item())},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(flat, cam, film, integ, res, xs)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 typedef enum {
     PT_OK = 0,
@@ -145,6 +145,12 @@ typedef struct {
     uint64_t node_visits;     /* slab tests executed (BVH._intersect_p calls) */
     uint64_t tri_tests;       /* Triangle.intersect/_p calls */
     uint64_t guard_nan, guard_neg, guard_inf;   /* renderer.py:185-193 */
+    uint64_t node_visits_any;  /* the share of node_visits / tri_tests spent on any-hit rays */
+    uint64_t tri_tests_any;
+    /* measurement only (no reference counterpart): filled when pt_set_profiling(ctx, 1) is on.
+     * Kernel time per stage from HIP events recorded on the caller's stream around each launch. */
+    uint64_t launches_trace_closest, launches_trace_any;
+    double ms_raygen, ms_trace_closest, ms_trace_any, ms_shade, ms_splat;
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;
@@ -184,6 +190,11 @@ int pt_render(pt_ctx *ctx, const pt_camera *cam, const pt_film_desc *film,
               const pt_sampler_desc *sampler, const pt_integrator_desc *integ,
               const pt_tile *tile, const double *sample_table, int32_t table_dims,
               double *film_accum, double *sample_L, pt_stats *stats, void *stream);
+
+/* No counterpart in the reference (it has no timers): measurement hook for
+ * bench.py.  When enabled, pt_render / pt_intersect bracket every kernel launch with HIP events
+ * on the caller's stream and add the per-stage totals to pt_stats (requires stats != NULL). */
+int pt_set_profiling(pt_ctx *ctx, int enable);
 
 /* replaces: the pixel loop of ImageFilm.write_image (film/film.py:237-256):
  * rgb[y][x] = max(0, xyz2rgb(Lxyz)/weight_sum).  film_accum device [y][x][4] → rgb device

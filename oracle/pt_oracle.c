@@ -233,7 +233,8 @@ int pto_intersect(void *scene, const double *rays, int64_t n, int any_hit,
     }
     if (stats) {
         stats->node_visits += nv; stats->tri_tests += nt;
-        if (any_hit) stats->rays_any += (uint64_t)n; else stats->rays_closest += (uint64_t)n;
+        if (any_hit) { stats->rays_any += (uint64_t)n; stats->node_visits_any += nv; stats->tri_tests_any += nt; }
+        else stats->rays_closest += (uint64_t)n;
     }
     return PT_OK;
 }
@@ -683,7 +684,8 @@ static int occluded(octx *c, const oray *r) {
     oray rr = *r; ohit h;
     uint64_t nv = 0, nt = 0;
     int hit = bvh_traverse(c->s, &rr, 1, &h, &nv, &nt);
-    if (c->st) { c->st->rays_any++; c->st->node_visits += nv; c->st->tri_tests += nt; }
+    if (c->st) { c->st->rays_any++; c->st->node_visits += nv; c->st->tri_tests += nt;
+                 c->st->node_visits_any += nv; c->st->tri_tests_any += nt; }
     return hit == 1;
 }
 static int closest(octx *c, oray *r, ohit *h) {

@@ -1,7 +1,7 @@
 """ctypes mirror of include/pytracer_hip.h (struct layouts and enums only)."""
 import ctypes as C
 
-PT_ABI_VERSION = 1
+PT_ABI_VERSION = 2
 PT_MAX_LOBES = 5
 
 PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
@@ -62,7 +62,17 @@ class pt_tile(C.Structure):
 class pt_stats(C.Structure):
     _fields_ = [('camera_samples', C.c_uint64), ('rays_closest', C.c_uint64), ('rays_any', C.c_uint64),
                 ('node_visits', C.c_uint64), ('tri_tests', C.c_uint64),
-                ('guard_nan', C.c_uint64), ('guard_neg', C.c_uint64), ('guard_inf', C.c_uint64)]
+                ('guard_nan', C.c_uint64), ('guard_neg', C.c_uint64), ('guard_inf', C.c_uint64),
+                ('node_visits_any', C.c_uint64), ('tri_tests_any', C.c_uint64),
+                ('launches_trace_closest', C.c_uint64), ('launches_trace_any', C.c_uint64),
+                ('ms_raygen', C.c_double), ('ms_trace_closest', C.c_double), ('ms_trace_any', C.c_double),
+                ('ms_shade', C.c_double), ('ms_splat', C.c_double)]
+
+    COUNTERS = ('camera_samples', 'rays_closest', 'rays_any', 'node_visits', 'tri_tests', 'guard_nan', 'guard_neg',
+                'guard_inf', 'node_visits_any', 'tri_tests_any')
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        return {k: int(getattr(self, k)) for k in self.COUNTERS}
+
+    def timing(self):
+        return {k: float(getattr(self, k)) for k, _ in self._fields_ if k.startswith('ms_')}

@@ -11,7 +11,7 @@ from . import _abi as A
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libpytracer_hip.so')
 
 EXPORTS = ('pt_version', 'pt_ctx_create', 'pt_ctx_destroy', 'pt_last_error', 'pt_scene_upload', 'pt_intersect',
-           'pt_render', 'pt_film_resolve')
+           'pt_render', 'pt_film_resolve', 'pt_set_profiling')
 
 _lib = None
 
@@ -45,6 +45,7 @@ def lib():
         L.pt_render.argtypes = [C.c_void_p, C.POINTER(A.pt_camera), C.POINTER(A.pt_film_desc),
                                 C.POINTER(A.pt_sampler_desc), C.POINTER(A.pt_integrator_desc), C.POINTER(A.pt_tile),
                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(A.pt_stats), C.c_void_p]
+        L.pt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pt_film_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         if L.pt_version() != A.PT_ABI_VERSION:
             raise ImportError('libpytracer_hip.so ABI %d != expected %d' % (L.pt_version(), A.PT_ABI_VERSION))
@@ -77,6 +78,9 @@ class Context(object):
     def _check(self, rc):
         if rc != 0:
             raise PtError(rc, lib().pt_last_error(self._h).decode('utf-8', 'replace'))
+
+    def set_profiling(self, enable):
+        self._check(lib().pt_set_profiling(self._h, int(bool(enable))))
 
     def upload(self, flat):
         d = flat.desc()

@@ -33,7 +33,14 @@ struct pt_ctx {
     RenderConst *d_rc;
     unsigned long long *d_counters;
     int n_cu;
+    // measurement (pt_set_profiling): event pairs around launches, tagged with a stage
+    bool profiling;
+    std::vector<hipEvent_t> *ev;     // pool, used pairwise
+    std::vector<int> *ev_stage;      // stage of pair k
+    size_t ev_used;
 };
+
+enum { STAGE_RAYGEN = 0, STAGE_TRACE_CLOSEST, STAGE_TRACE_ANY, STAGE_SHADE, STAGE_SPLAT, STAGE_COUNT };
 
 static int fail(pt_ctx *c, int code, const char *fmt, ...) {
     if (c) {
@@ -88,8 +95,56 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     CREATE_CHK(hipMalloc((void **)&c->d_counts, 3 * sizeof(int)));
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
     CREATE_CHK(hipMalloc((void **)&c->d_counters, CNT_COUNT * sizeof(unsigned long long)));
+    c->ev = new std::vector<hipEvent_t>();
+    c->ev_stage = new std::vector<int>();
     *out = c;
     return PT_OK;
+}
+
+extern "C" int pt_set_profiling(pt_ctx *c, int enable) {
+    if (!c) return PT_ERR_ARG;
+    c->profiling = enable != 0;
+    return PT_OK;
+}
+
+// Brackets one launch with a pair of events on `stream` (no-op unless profiling).
+struct StageTimer {
+    pt_ctx *c;
+    hipStream_t stream;
+    bool on;
+    StageTimer(pt_ctx *c_, hipStream_t s, int stage) : c(c_), stream(s), on(c_->profiling) {
+        if (!on) return;
+        if (c->ev_used + 2 > c->ev->size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            c->ev->push_back(a);
+            c->ev->push_back(b);
+        }
+        if (c->ev_stage->size() < c->ev_used / 2 + 1) c->ev_stage->push_back(stage);
+        else (*c->ev_stage)[c->ev_used / 2] = stage;
+        (void)hipEventRecord((*c->ev)[c->ev_used], stream);
+    }
+    ~StageTimer() {
+        if (!on) return;
+        (void)hipEventRecord((*c->ev)[c->ev_used + 1], stream);
+        c->ev_used += 2;
+    }
+};
+
+static void collect_timing(pt_ctx *c, pt_stats *stats) {
+    // caller has synchronised the stream
+    for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, (*c->ev)[k], (*c->ev)[k + 1]) != hipSuccess) continue;
+        switch ((*c->ev_stage)[k / 2]) {
+        case STAGE_RAYGEN: stats->ms_raygen += ms; break;
+        case STAGE_TRACE_CLOSEST: stats->ms_trace_closest += ms; stats->launches_trace_closest++; break;
+        case STAGE_TRACE_ANY: stats->ms_trace_any += ms; stats->launches_trace_any++; break;
+        case STAGE_SHADE: stats->ms_shade += ms; break;
+        default: stats->ms_splat += ms; break;
+        }
+    }
+    c->ev_used = 0;
 }
 
 static void free_scene(pt_ctx *c) {
@@ -109,6 +164,8 @@ extern "C" int pt_ctx_destroy(pt_ctx *c) {
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_rc) (void)hipFree(c->d_rc);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->ev) { for (hipEvent_t e : *c->ev) (void)hipEventDestroy(e); delete c->ev; }
+    delete c->ev_stage;
     free(c);
     return PT_OK;
 }
@@ -256,6 +313,9 @@ static int read_counters(pt_ctx *c, hipStream_t stream, pt_stats *stats) {
     stats->guard_nan += h[CNT_GUARD_NAN];
     stats->guard_neg += h[CNT_GUARD_NEG];
     stats->guard_inf += h[CNT_GUARD_INF];
+    stats->node_visits_any += h[CNT_NODE_VISITS_ANY];
+    stats->tri_tests_any += h[CNT_TRI_TESTS_ANY];
+    if (c->profiling) collect_timing(c, stats);
     return PT_OK;
 }
 
@@ -274,8 +334,12 @@ extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hi
         cnt = c->d_counters;
     }
     ShadowResolve rs = {nullptr, 0, nullptr, nullptr, 0};
-    HIPCHK(c, pt_launch_trace(any_hit != 0, c->stack_need, trace_grid(c, n), stream, c->sc, rays, (long)n, nullptr,
-                              (int)n, prim, t, b1, b2, rs, cnt));
+    c->ev_used = 0;
+    {
+        StageTimer tm(c, stream, any_hit ? STAGE_TRACE_ANY : STAGE_TRACE_CLOSEST);
+        HIPCHK(c, pt_launch_trace(any_hit != 0, c->stack_need, trace_grid(c, n), stream, c->sc, rays, (long)n, nullptr,
+                                  (int)n, prim, t, b1, b2, rs, cnt));
+    }
     if (stats) return read_counters(c, stream, stats);
     return PT_OK;
 }
@@ -396,33 +460,53 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     else levels = c->has_spec_reflect ? std::max(ig->max_depth, 1) : 1;
 
     const ShadowResolve no_rs = {nullptr, 0, nullptr, nullptr, 0};
+    c->ev_used = 0;
     for (long base = 0; base < total; base += batch) {
         const int nb = (int)std::min(batch, total - base);
         const int g = (nb + PT_BLOCK - 1) / PT_BLOCK;
         const int gt = trace_grid(c, nb);
-        HIPCHK(c, pt_launch_raygen(g, stream, c->d_rc, base, nb, c->q[0], c->st, cnt));
+        {
+            StageTimer tm(c, stream, STAGE_RAYGEN);
+            HIPCHK(c, pt_launch_raygen(g, stream, c->d_rc, base, nb, c->q[0], c->st, cnt));
+        }
         HIPCHK(c, pt_launch_set_int(stream, c->q[0].count, nb));
-        if (ig->pretest)   // renderer.py:168: same hit flag as the closest-hit pass below
+        if (ig->pretest) {   // renderer.py:168: same hit flag as the closest-hit pass below
+            StageTimer tm(c, stream, STAGE_TRACE_ANY);
             HIPCHK(c, pt_launch_trace(true, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
                                       nb, nullptr, nullptr, nullptr, nullptr, no_rs, cnt));
-        HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr, nb,
-                                  c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
+        }
+        {
+            StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
+            HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
+                                      nb, c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
+        }
         int cur = 0;
         for (int level = 0; level < levels; level++) {
             Queue &qin = c->q[cur], &qout = c->q[cur ^ 1];
             HIPCHK(c, hipMemsetAsync(qout.count, 0, sizeof(int), stream));
             HIPCHK(c, hipMemsetAsync(c->sh.count, 0, sizeof(int), stream));
-            HIPCHK(c, pt_launch_shade(ig->kind, gt, stream, c->sc, c->d_rc, base, level, qin, qout, c->sh, c->st));
+            {
+                StageTimer tm(c, stream, STAGE_SHADE);
+                HIPCHK(c, pt_launch_shade(ig->kind, gt, stream, c->sc, c->d_rc, base, level, qin, qout, c->sh, c->st));
+            }
             ShadowResolve rs = {c->sh.c, c->sh.stride, c->sh.slot, c->st.L, c->st.stride};
-            HIPCHK(c, pt_launch_trace(true, c->stack_need, trace_grid(c, (long)nb * spv), stream, c->sc, c->sh.rays,
-                                      c->sh.stride, c->sh.count, 0, nullptr, nullptr, nullptr, nullptr, rs, cnt));
+            {
+                StageTimer tm(c, stream, STAGE_TRACE_ANY);
+                HIPCHK(c, pt_launch_trace(true, c->stack_need, trace_grid(c, (long)nb * spv), stream, c->sc,
+                                          c->sh.rays, c->sh.stride, c->sh.count, 0, nullptr, nullptr, nullptr, nullptr,
+                                          rs, cnt));
+            }
             if (level + 1 < levels) {
+                StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
                 HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, qout.rays, qout.stride, qout.count,
                                           0, qout.prim, qout.t, qout.b1, qout.b2, no_rs, cnt));
                 cur ^= 1;
             }
         }
-        HIPCHK(c, pt_launch_splat(g, stream, c->d_rc, nb, c->st, film_accum, sample_L, base, cnt));
+        {
+            StageTimer tm(c, stream, STAGE_SPLAT);
+            HIPCHK(c, pt_launch_splat(stream, c->d_rc, *tile, *film, base, nb, c->st, film_accum, sample_L, cnt));
+        }
     }
     if (stats) return read_counters(c, stream, stats);
     return PT_OK;

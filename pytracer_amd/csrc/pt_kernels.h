@@ -15,6 +15,8 @@ enum {
     CNT_GUARD_NAN,
     CNT_GUARD_NEG,
     CNT_GUARD_INF,
+    CNT_NODE_VISITS_ANY,
+    CNT_TRI_TESTS_ANY,
     CNT_COUNT
 };
 
@@ -80,7 +82,8 @@ hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc,
 hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,
                            int level, const Queue &qin, const Queue &qout, const ShadowQueue &sh,
                            const PathState &st);
-hipError_t pt_launch_splat(int grid, hipStream_t stream, const RenderConst *rc, int nb, const PathState &st,
-                           double *film, double *sample_L, long base_out, unsigned long long *counters);
+hipError_t pt_launch_splat(hipStream_t stream, const RenderConst *rc, const pt_tile &tile, const pt_film_desc &fm,
+                           long base, int nb, const PathState &st, double *film, double *sample_L,
+                           unsigned long long *counters);
 hipError_t pt_launch_film_resolve(hipStream_t stream, const double *acc, long npix, double *rgb);
 hipError_t pt_launch_set_int(hipStream_t stream, int *p, int v);

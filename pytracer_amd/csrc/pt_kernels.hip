@@ -132,6 +132,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene sc, const double *__r
             atomicAdd(counters + CNT_NODE_VISITS, v);
             atomicAdd(counters + CNT_TRI_TESTS, w);
             atomicAdd(counters + (ANY ? CNT_RAYS_ANY : CNT_RAYS_CLOSEST), x);
+            if (ANY) {
+                atomicAdd(counters + CNT_NODE_VISITS_ANY, v);
+                atomicAdd(counters + CNT_TRI_TESTS_ANY, w);
+            }
         }
     }
 }
@@ -495,62 +499,135 @@ hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene 
 // =========================================================================================
 // K7 film splat: the radiance guards of SamplerRendererTask.__call__ (renderer/renderer.py:
 // 185-193) + ImageFilm.add_sample (film/film.py:137-198).  film_accum[y][x][4] f64.
+//
+// One workgroup owns a strip of SPLAT_PX consecutive pixels of one image row and all samples
+// of those pixels that lie in the current batch.  Footprints (9x9 pixels for the 4-pixel
+// Lanczos of the examples) are accumulated with LDS f64 atomics into a component-major LDS
+// tile of (SPLAT_PX + 2*hx) x (2*hy + 1) pixels — lanes map to DIFFERENT pixels of the strip so
+// that a wave's 64 simultaneous adds go to distinct LDS addresses — and the tile is flushed
+// once with global f64 atomics: ~0.7 global atomics per sample instead of 324.
 // =========================================================================================
-__global__ __launch_bounds__(PT_BLOCK) void k_splat(const RenderConst *__restrict__ rcp, int nb, PathState st,
-                                                    double *__restrict__ film, double *__restrict__ sample_L,
-                                                    long base_out, unsigned long long *counters) {
-    const RenderConst &rc = *rcp;
-    const int i = blockIdx.x * PT_BLOCK + threadIdx.x;
-    if (i >= nb) return;
-    const long P = st.stride;
-    d3 L = mk3(st.L[i], st.L[P + i], st.L[2 * P + i]);
+#define SPLAT_PX 32
+
+__device__ __forceinline__ d3 guarded_radiance(d3 L, unsigned long long *counters) {
     if (isnan(L.x) || isnan(L.y) || isnan(L.z)) {
-        L = mk3(0, 0, 0);
         if (counters) atomicAdd(counters + CNT_GUARD_NAN, 1ull);
-    } else if (spec_y(L) < -PT_EPS) {
-        L = mk3(0, 0, 0);
+        return mk3(0, 0, 0);
+    }
+    const double y = spec_y(L);
+    if (y < -PT_EPS) {
         if (counters) atomicAdd(counters + CNT_GUARD_NEG, 1ull);
-    } else if (spec_y(L) == __builtin_inf()) {
-        L = mk3(0, 0, 0);
+        return mk3(0, 0, 0);
+    }
+    if (y == __builtin_inf()) {
         if (counters) atomicAdd(counters + CNT_GUARD_INF, 1ull);
+        return mk3(0, 0, 0);
     }
-    if (sample_L) {
-        sample_L[3 * (base_out + i)] = L.x;
-        sample_L[3 * (base_out + i) + 1] = L.y;
-        sample_L[3 * (base_out + i) + 2] = L.z;
-    }
-    if (!film) return;
+    return L;
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void k_splat(const RenderConst *__restrict__ rcp, long base, int nb,
+                                                    int row_first, int hx, int hy, int use_lds, PathState st,
+                                                    double *__restrict__ film, double *__restrict__ sample_L,
+                                                    unsigned long long *counters) {
+    extern __shared__ double s_tile[];   // [4][th][tw_l]
+    const RenderConst &rc = *rcp;
     const pt_film_desc &fm = rc.film;
-    const double dX = st.img[i] - .5, dY = st.img[P + i] - .5;
-    int x0 = (int)ceil(dX - fm.xw), x1 = (int)floor(dX + fm.xw);
-    int y0 = (int)ceil(dY - fm.yw), y1 = (int)floor(dY + fm.yw);
-    x0 = max(x0, fm.x_start); x1 = min(x1, fm.x_start + fm.x_cnt - 1);
-    y0 = max(y0, fm.y_start); y1 = min(y1, fm.y_start + fm.y_cnt - 1);
-    if (x1 - x0 < 0 || y1 - y0 < 0) return;
-    // rgb2xyz, spectral/spectrum.py:31-34
-    const double X = (0.412453 * L.x + 0.357580 * L.y) + 0.180423 * L.z;
-    const double Y = (0.212671 * L.x + 0.715160 * L.y) + 0.072169 * L.z;
-    const double Z = (0.019334 * L.x + 0.119193 * L.y) + 0.950227 * L.z;
+    const int tw = rc.tile.x1 - rc.tile.x0, ns = rc.tile.s1 - rc.tile.s0;
+    const int nchunks = (tw + SPLAT_PX - 1) / SPLAT_PX;
+    const int row = row_first + (int)(blockIdx.x / nchunks);          // row inside the tile
+    const int cx0 = (int)(blockIdx.x % nchunks) * SPLAT_PX;           // first strip pixel inside the tile
+    const int py = rc.tile.y0 + row;
+    const int tw_l = SPLAT_PX + 2 * hx, th_l = 2 * hy + 1;
+    const int lx0 = rc.tile.x0 + cx0 - hx, ly0 = py - hy;             // film coords of LDS tile origin
+    const int plane = tw_l * th_l;
+    if (use_lds) {
+        for (int k = threadIdx.x; k < 4 * plane; k += PT_BLOCK) s_tile[k] = 0.;
+        __syncthreads();
+    }
+    const int q = threadIdx.x % SPLAT_PX, sub = threadIdx.x / SPLAT_PX;
+    const int px_t = cx0 + q;                                         // pixel column inside the tile
+    const long P = st.stride;
     const double xwInv = 1. / fm.xw, ywInv = 1. / fm.yw;
-    for (int y = y0; y <= y1; y++) {
-        int ify = (int)floor(fabs((y - dY) * 16 * ywInv));
-        ify = min(ify, 15);
-        for (int x = x0; x <= x1; x++) {
-            int ifx = (int)floor(fabs((x - dX) * 16 * xwInv));
-            ifx = min(ifx, 15);
-            const double wt = rc.film.table[ify * 16 + ifx];
-            double *px = film + 4 * ((size_t)(y - fm.y_start) * fm.x_cnt + (x - fm.x_start));
-            unsafeAtomicAdd(px + 0, wt * X);
-            unsafeAtomicAdd(px + 1, wt * Y);
-            unsafeAtomicAdd(px + 2, wt * Z);
-            unsafeAtomicAdd(px + 3, wt);
+    const int fx1 = fm.x_start + fm.x_cnt - 1, fy1 = fm.y_start + fm.y_cnt - 1;
+    if (px_t < tw) {
+        const long pix_i = ((long)row * tw + px_t) * ns;
+        for (int s = sub; s < ns; s += PT_BLOCK / SPLAT_PX) {
+            const long out_i = pix_i + s;
+            if (out_i < base || out_i >= base + nb) continue;
+            const int slot = (int)(out_i - base);
+            d3 L = guarded_radiance(mk3(st.L[slot], st.L[P + slot], st.L[2 * P + slot]), counters);
+            if (sample_L) {
+                sample_L[3 * out_i] = L.x; sample_L[3 * out_i + 1] = L.y; sample_L[3 * out_i + 2] = L.z;
+            }
+            if (!film) continue;
+            const double dX = st.img[slot] - .5, dY = st.img[P + slot] - .5;
+            int x0 = (int)ceil(dX - fm.xw), x1 = (int)floor(dX + fm.xw);
+            int y0 = (int)ceil(dY - fm.yw), y1 = (int)floor(dY + fm.yw);
+            x0 = max(x0, fm.x_start); x1 = min(x1, fx1);
+            y0 = max(y0, fm.y_start); y1 = min(y1, fy1);
+            if (x1 - x0 < 0 || y1 - y0 < 0) continue;
+            // rgb2xyz, spectral/spectrum.py:31-34
+            const double X = (0.412453 * L.x + 0.357580 * L.y) + 0.180423 * L.z;
+            const double Y = (0.212671 * L.x + 0.715160 * L.y) + 0.072169 * L.z;
+            const double Z = (0.019334 * L.x + 0.119193 * L.y) + 0.950227 * L.z;
+            const bool in_tile = use_lds && x0 >= lx0 && x1 < lx0 + tw_l && y0 >= ly0 && y1 < ly0 + th_l;
+            for (int y = y0; y <= y1; y++) {
+                int ify = (int)floor(fabs((y - dY) * 16 * ywInv));
+                ify = min(ify, 15);
+                for (int x = x0; x <= x1; x++) {
+                    int ifx = (int)floor(fabs((x - dX) * 16 * xwInv));
+                    ifx = min(ifx, 15);
+                    const double wt = fm.table[ify * 16 + ifx];
+                    if (in_tile) {
+                        double *t = s_tile + (y - ly0) * tw_l + (x - lx0);
+                        unsafeAtomicAdd(t, wt * X);
+                        unsafeAtomicAdd(t + plane, wt * Y);
+                        unsafeAtomicAdd(t + 2 * plane, wt * Z);
+                        unsafeAtomicAdd(t + 3 * plane, wt);
+                    } else {
+                        double *g = film + 4 * ((size_t)(y - fm.y_start) * fm.x_cnt + (x - fm.x_start));
+                        unsafeAtomicAdd(g + 0, wt * X);
+                        unsafeAtomicAdd(g + 1, wt * Y);
+                        unsafeAtomicAdd(g + 2, wt * Z);
+                        unsafeAtomicAdd(g + 3, wt);
+                    }
+                }
+            }
         }
+    }
+    if (!use_lds || !film) return;
+    __syncthreads();
+    for (int k = threadIdx.x; k < plane; k += PT_BLOCK) {
+        const int y = ly0 + k / tw_l, x = lx0 + k % tw_l;
+        if (x < fm.x_start || x > fx1 || y < fm.y_start || y > fy1) continue;
+        const double w = s_tile[3 * plane + k];
+        const double a = s_tile[k], b = s_tile[plane + k], c = s_tile[2 * plane + k];
+        if (w == 0. && a == 0. && b == 0. && c == 0.) continue;
+        double *g = film + 4 * ((size_t)(y - fm.y_start) * fm.x_cnt + (x - fm.x_start));
+        unsafeAtomicAdd(g + 0, a);
+        unsafeAtomicAdd(g + 1, b);
+        unsafeAtomicAdd(g + 2, c);
+        unsafeAtomicAdd(g + 3, w);
     }
 }
 
-hipError_t pt_launch_splat(int grid, hipStream_t stream, const RenderConst *rc, int nb, const PathState &st,
-                           double *film, double *sample_L, long base_out, unsigned long long *counters) {
-    hipLaunchKernelGGL(k_splat, dim3(grid), dim3(PT_BLOCK), 0, stream, rc, nb, st, film, sample_L, base_out, counters);
+hipError_t pt_launch_splat(hipStream_t stream, const RenderConst *rc, const pt_tile &tile, const pt_film_desc &fm,
+                           long base, int nb, const PathState &st, double *film, double *sample_L,
+                           unsigned long long *counters) {
+    const int tw = tile.x1 - tile.x0, ns = tile.s1 - tile.s0;
+    const long per_row = (long)tw * ns;
+    const int row_first = (int)(base / per_row), row_last = (int)((base + nb - 1) / per_row);
+    const int nchunks = (tw + SPLAT_PX - 1) / SPLAT_PX;
+    // samples of pixel p lie in [p, p+1): dX in [p-.5, p+.5) so the footprint reaches at most
+    // ceil(w + .5) pixels to either side (anything beyond falls back to global atomics)
+    int hx = (int)ceil(fm.xw + .5), hy = (int)ceil(fm.yw + .5);
+    size_t lds = (size_t)4 * (SPLAT_PX + 2 * hx) * (2 * hy + 1) * sizeof(double);
+    int use_lds = lds <= 48 * 1024;
+    if (!use_lds) { hx = hy = 0; lds = 0; }
+    const int grid = (row_last - row_first + 1) * nchunks;
+    hipLaunchKernelGGL(k_splat, dim3(grid), dim3(PT_BLOCK), lds, stream, rc, base, nb, row_first, hx, hy, use_lds, st,
+                       film, sample_L, counters);
     return hipGetLastError();
 }
 

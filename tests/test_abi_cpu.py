@@ -79,3 +79,17 @@ def test_flat_scene_rejects_bad_tree(golden_dir):
     d2 = dict(d, node_meta=meta)
     with pytest.raises(ValueError):
         pa.flat_scene_from_npz(d2)
+
+
+def test_host_camera_and_film_match_reference_fixture(golden_dir):
+    """pytracer_amd.host restates PerspectiveCamera/ImageFilm construction; the fixture holds the
+    matrices and the Lanczos table the reference built for the 128x128 head-mesh camera."""
+    from pytracer_amd import host
+    d = dict(np.load(os.path.join(golden_dir, 'head_mesh_scene.npz')))
+    cam, film = host.head_mesh_camera_film(128, 128)
+    np.testing.assert_allclose(np.array(cam.r2c).reshape(4, 4), d['cam_r2c'], rtol=1e-13, atol=1e-18)
+    np.testing.assert_allclose(np.array(cam.c2w).reshape(4, 4), d['cam_c2w'], rtol=0, atol=0)
+    np.testing.assert_allclose(np.array(cam.dx), d['cam_dx'], rtol=1e-12, atol=1e-20)
+    np.testing.assert_allclose(np.array(cam.dy), d['cam_dy'], rtol=1e-12, atol=1e-20)
+    np.testing.assert_allclose(np.array(film.table).reshape(16, 16), d['filt_table'], rtol=1e-14, atol=1e-18)
+    assert (film.x_start, film.x_cnt, film.y_start, film.y_cnt) == tuple(int(v) for v in d['film_win'])
