@@ -1,0 +1,98 @@
+"""GpuSamplerRenderer on reference-shaped objects (the reference itself is not on the GPU box):
+render(scene) fills film.pixels like SamplerRendererTask + ImageFilm.add_sample would."""
+import os
+
+import numpy as np
+import pytest
+
+import pytracer_amd as pa
+from pytracer_amd import _abi as A
+from pytracer_amd.renderer import GpuSamplerRenderer, host_sample_table
+import standin
+
+pytestmark = pytest.mark.gpu
+
+
+def film_arrays(film):
+    W, H = film.xPixel_cnt, film.yPixel_cnt
+    acc = np.zeros((H, W, 4))
+    for x in range(W):
+        for y in range(H):
+            acc[y, x, 0:3] = film.pixels[x][y].Lxyz
+            acc[y, x, 3] = film.pixels[x][y].weight_sum
+    return acc
+
+
+@pytest.mark.parametrize('kind', ['direct', 'path'])
+def test_renderer_fills_film_like_the_oracle(golden_dir, kind):
+    import oracle_lib as O
+    d = dict(np.load(os.path.join(golden_dir, 'head_mesh_scene.npz')))
+    scene = standin.build_scene(d)
+    camera = standin.build_camera(d)
+    sampler = standin.build_sampler(30, 94, 30, 94, 2, 1)
+    integ = standin.build_integrator(kind)
+    ren = GpuSamplerRenderer(sampler, camera, integ, None, device=0, seed=11)
+    assert ren.render(scene) is None
+    assert camera.film.written == 1
+    got = film_arrays(camera.film)
+    flat = pa.flat_scene_from_npz(d)
+    cam, film = pa.camera_film_from_npz(d)
+    smp = pa.sampler_desc(30, 94, 30, 94, 2, 1, True, 11)
+    ig = pa.integrator_desc(A.PT_INTEG_PATH if kind == 'path' else A.PT_INTEG_DIRECT, 5, False)
+    ref, _ = O.OracleScene(flat).render(cam, film, smp, ig, pa.tile_desc(30, 94, 30, 94, 0, 2), want_L=False)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12)
+    assert ren.stats.camera_samples == 64 * 64 * 2
+    # a second render into the same film accumulates, like add_sample does
+    ren.render(scene)
+    np.testing.assert_allclose(film_arrays(camera.film), 2 * ref, rtol=1e-9, atol=1e-12)
+
+
+def test_renderer_with_host_sampler_protocol(golden_dir):
+    """sampler_mode='host': any object with generate(samples) drives the GPU path through the
+    sample-table (parity) interface; here the captured reference stream is replayed."""
+    d = dict(np.load(os.path.join(golden_dir, 'head_direct_24x24x4.npz')))
+    sc = dict(np.load(os.path.join(golden_dir, 'head_mesh_scene.npz')))
+
+    class ReplaySampler(object):
+        """StratifiedSampler-shaped object that replays the fixture's captured samples."""
+        xPixel_start, xPixel_end, yPixel_start, yPixel_end = 0, 24, 0, 24
+        xSamples = ySamples = 2
+        jitter, s_open, s_close, spp = True, 0., 0., 4
+
+        def __init__(self):
+            self.pos = 0
+
+        def maximum_sample_cnt(self):
+            return 4
+
+        def generate(self, samples):
+            if self.pos >= len(d['samples']):
+                return False
+            for s in samples:
+                row = d['samples'][self.pos]
+                s.imageX, s.imageY, s.lens_u, s.lens_v, s.time = row[0:5]
+                o = 5
+                for j, n in enumerate(s.n1D):
+                    s.oneD[j] = row[o:o + n]; o += n
+                for j, n in enumerate(s.n2D):
+                    s.twoD[j] = row[o:o + 2 * n].reshape(n, 2); o += 2 * n
+                self.pos += 1
+            return True
+    ReplaySampler.__name__ = 'StratifiedSampler'
+
+    class Integ(object):
+        max_depth = 5
+
+        def request_samples(self, sampler, sample, scene):     # direct.py:46-62
+            for light in scene.lights:
+                sample.add_1d(light.ns); sample.add_2d(light.ns)
+                sample.add_1d(light.ns); sample.add_2d(light.ns)
+    Integ.__name__ = 'DirectLightingIntegrator'
+
+    scene = standin.build_scene(sc)
+    camera = standin.build_camera(d)
+    ren = GpuSamplerRenderer(ReplaySampler(), camera, Integ(), None, device=0, sampler_mode='host', pretest=True)
+    ren.render(scene)
+    got = film_arrays(camera.film)
+    np.testing.assert_allclose(got[..., 0:3], d['film_Lxyz'], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(got[..., 3], d['film_wsum'], rtol=1e-4, atol=1e-9)

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 (rocpd sqlite) outputs into the tracked files under profiles/.
+
+    python3 tools/prof_summary.py <round-tag> <stats.db> [<fetch.db> <write.db>]
+
+Writes profiles/<tag>_kernel_stats.csv (the `--kernel-trace --stats` table) and, when the two
+PMC passes are given, profiles/<tag>_pmc.csv plus profiles/pmc_summary.json, which bench.py
+reads for `roofline.traffic`.  HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB → bytes):
+on gfx950 FETCH_SIZE reports half the bytes of wide reads (MI355X_MICROARCH.md §HBM); the
+factor is calibrated for 16-B-per-lane streaming reads and is applied here to the 16-B-per-lane
+gather reads of the traversal kernels as the guide prescribes, WRITE_SIZE is exact.
+"""
+import csv
+import json
+import os
+import re
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    m = re.match(r'(?:void )?(k_trace)<(\d+), (true|false)>', name)
+    if m:
+        return 'k_trace<%s>' % ('any' if m.group(3) == 'true' else 'closest')
+    m = re.match(r'(?:void )?(k_[a-z_]+)(<\d+>)?', name)
+    return (m.group(1) + (m.group(2) or '')) if m else name[:60]
+
+
+def main():
+    tag, stats_db = sys.argv[1], sys.argv[2]
+    out = os.path.join(ROOT, 'profiles')
+    os.makedirs(out, exist_ok=True)
+    con = sqlite3.connect(stats_db)
+    rows = list(con.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
+    with open(os.path.join(out, tag + '_kernel_stats.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'calls', 'total_us', 'avg_us', 'percent', 'full_name'])
+        for n, c, t, a, p in rows:
+            w.writerow([short(n), c, '%.3f' % t, '%.3f' % a, '%.3f' % p, n])
+    res = list(con.execute('select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, '
+                           'workgroup_x, min(grid_x), max(grid_x) from kernels group by name'))
+    with open(os.path.join(out, tag + '_kernel_resources.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'vgpr', 'agpr', 'sgpr', 'lds_bytes', 'scratch_bytes', 'workgroup', 'grid_min', 'grid_max'])
+        for r in res:
+            w.writerow([short(r[0])] + list(r[1:]))
+    if len(sys.argv) >= 5:
+        agg = {}
+        for which, db in (('FETCH_SIZE', sys.argv[3]), ('WRITE_SIZE', sys.argv[4])):
+            c2 = sqlite3.connect(db)
+            q = ("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
+                 "group by kernel_name")
+            for n, cnt, v in c2.execute(q, (which,)):
+                a = agg.setdefault(short(n), {})
+                a[which + '_KB'] = v
+                a[which + '_launches'] = cnt
+        summary = {}
+        with open(os.path.join(out, tag + '_pmc.csv'), 'w', newline='') as f:
+            w = csv.writer(f)
+            w.writerow(['kernel', 'launches', 'FETCH_SIZE_KB_total', 'WRITE_SIZE_KB_total', 'hbm_bytes_per_launch'])
+            for k, a in sorted(agg.items()):
+                if not k.startswith('k_'):
+                    continue
+                n = a.get('FETCH_SIZE_launches') or a.get('WRITE_SIZE_launches')
+                fk, wk = a.get('FETCH_SIZE_KB', 0.), a.get('WRITE_SIZE_KB', 0.)
+                per = (2. * fk + wk) * 1024. / max(n, 1)
+                w.writerow([k, n, '%.1f' % fk, '%.1f' % wk, '%.0f' % per])
+                summary[k] = {'launches': n, 'fetch_kb_total': fk, 'write_kb_total': wk, 'hbm_bytes_per_launch': per,
+                              'source': 'profiles/%s_pmc.csv' % tag}
+        json.dump(summary, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()
