@@ -9,6 +9,8 @@ import os
 from . import _abi as A
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libpytracer_hip.so')
+if os.environ.get('PYTRACER_HIP_LIB'):        # kernel A/B experiments only (scripts/ab_libs.sh)
+    LIB_PATH = os.path.abspath(os.environ['PYTRACER_HIP_LIB'])
 
 EXPORTS = ('pt_version', 'pt_ctx_create', 'pt_ctx_destroy', 'pt_last_error', 'pt_scene_upload', 'pt_intersect',
            'pt_render', 'pt_film_resolve', 'pt_set_profiling')

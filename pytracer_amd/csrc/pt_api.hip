@@ -29,7 +29,8 @@ struct pt_ctx {
     Queue q[2];
     ShadowQueue sh;
     PathState st;
-    int *d_counts;           // [3]: q0, q1, shadow
+    int *d_counts;           // [4]: q0, q1, shadow, next-ray counter of the dynamic-fetch trace kernel
+    int trace_variant;       // 0: per-ray loop, 1: while-while + dynamic fetch (PT_TRACE_VARIANT)
     RenderConst *d_rc;
     unsigned long long *d_counters;
     int n_cu;
@@ -92,9 +93,11 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    CREATE_CHK(hipMalloc((void **)&c->d_counts, 3 * sizeof(int)));
+    CREATE_CHK(hipMalloc((void **)&c->d_counts, 4 * sizeof(int)));
+    c->trace_variant = 0;
+    if (const char *e = getenv("PT_TRACE_VARIANT")) c->trace_variant = atoi(e);
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
-    CREATE_CHK(hipMalloc((void **)&c->d_counters, CNT_COUNT * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc((void **)&c->d_counters, PT_CNT_SHARDS * CNT_COUNT * sizeof(unsigned long long)));
     c->ev = new std::vector<hipEvent_t>();
     c->ev_stage = new std::vector<int>();
     *out = c;
@@ -302,9 +305,14 @@ static int trace_grid(const pt_ctx *c, long n) {
 }
 
 static int read_counters(pt_ctx *c, hipStream_t stream, pt_stats *stats) {
-    unsigned long long h[CNT_COUNT];
-    HIPCHK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, stream));
+    static_assert(CNT_COUNT <= 16, "counter block");
+    std::vector<unsigned long long> sh((size_t)PT_CNT_SHARDS * CNT_COUNT);
+    HIPCHK(c, hipMemcpyAsync(sh.data(), c->d_counters, sh.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                             stream));
     HIPCHK(c, hipStreamSynchronize(stream));
+    unsigned long long h[CNT_COUNT] = {0};
+    for (int k = 0; k < PT_CNT_SHARDS; k++)
+        for (int j = 0; j < CNT_COUNT; j++) h[j] += sh[(size_t)k * CNT_COUNT + j];
     stats->node_visits += h[CNT_NODE_VISITS];
     stats->tri_tests += h[CNT_TRI_TESTS];
     stats->rays_closest += h[CNT_RAYS_CLOSEST];
@@ -330,14 +338,14 @@ extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hi
     HIPCHK(c, hipSetDevice(c->device));
     unsigned long long *cnt = nullptr;
     if (stats) {
-        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, CNT_COUNT * sizeof(unsigned long long), stream));
+        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, PT_CNT_SHARDS * CNT_COUNT * sizeof(unsigned long long), stream));
         cnt = c->d_counters;
     }
     ShadowResolve rs = {nullptr, 0, nullptr, nullptr, 0};
     c->ev_used = 0;
     {
         StageTimer tm(c, stream, any_hit ? STAGE_TRACE_ANY : STAGE_TRACE_CLOSEST);
-        HIPCHK(c, pt_launch_trace(any_hit != 0, c->stack_need, trace_grid(c, n), stream, c->sc, rays, (long)n, nullptr,
+        HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, any_hit != 0, c->stack_need, trace_grid(c, n), stream, c->sc, rays, (long)n, nullptr,
                                   (int)n, prim, t, b1, b2, rs, cnt));
     }
     if (stats) return read_counters(c, stream, stats);
@@ -439,8 +447,20 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(c, hipSetDevice(c->device));
 
-    long batch = 1l << 22;
+    // paths in flight per wavefront pass.  288 GB of HBM makes a whole 1024^2 x 64 spp render
+    // (67 M paths, ~430 B of state each ≈ 29 GB) one batch, which amortises the latency-bound
+    // tails of the sparsely populated deep-bounce launches over 16x more work.
+    long batch = 1l << 26;
     if (const char *e = getenv("PT_BATCH")) { long v = atol(e); if (v >= 64) batch = v; }
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t per_path = 8 * 8 * 2 + 4 * 2 * 2 + 8 * 3 * 2 + (8 * 11 + 4) * (size_t)std::max(1, ig->kind == PT_INTEG_DIRECT ? c->shadow_per_vertex_direct : 1) + 8 * 8;
+            const size_t budget = (free_b + c->ws_bytes) / 2;     // leave half of what is free to the caller
+            const long fit = (long)(budget / per_path);
+            if (fit < batch) batch = std::max(fit, 1l << 16);
+        }
+    }
     batch = std::min(batch, total);
     batch = (batch + 63) & ~63l;
     const int spv = ig->kind == PT_INTEG_DIRECT ? std::max(c->shadow_per_vertex_direct, 1) : 1;
@@ -450,7 +470,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     HIPCHK(c, hipMemcpyAsync(c->d_rc, &h, sizeof(h), hipMemcpyHostToDevice, stream));
     unsigned long long *cnt = nullptr;
     if (stats) {
-        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, CNT_COUNT * sizeof(unsigned long long), stream));
+        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, PT_CNT_SHARDS * CNT_COUNT * sizeof(unsigned long long), stream));
         cnt = c->d_counters;
     }
     // number of shade levels: Path shades bounce 0..max_depth; Direct recurses only through
@@ -472,12 +492,12 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         HIPCHK(c, pt_launch_set_int(stream, c->q[0].count, nb));
         if (ig->pretest) {   // renderer.py:168: same hit flag as the closest-hit pass below
             StageTimer tm(c, stream, STAGE_TRACE_ANY);
-            HIPCHK(c, pt_launch_trace(true, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
+            HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, true, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
                                       nb, nullptr, nullptr, nullptr, nullptr, no_rs, cnt));
         }
         {
             StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-            HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
+            HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, false, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
                                       nb, c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
         }
         int cur = 0;
@@ -492,13 +512,20 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             ShadowResolve rs = {c->sh.c, c->sh.stride, c->sh.slot, c->st.L, c->st.stride};
             {
                 StageTimer tm(c, stream, STAGE_TRACE_ANY);
-                HIPCHK(c, pt_launch_trace(true, c->stack_need, trace_grid(c, (long)nb * spv), stream, c->sc,
+                HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, true, c->stack_need, trace_grid(c, (long)nb * spv), stream, c->sc,
                                           c->sh.rays, c->sh.stride, c->sh.count, 0, nullptr, nullptr, nullptr, nullptr,
                                           rs, cnt));
             }
+            if (getenv("PT_DEBUG_LEVELS") && base == 0) {   // debugging aid: queue sizes per level (syncs)
+                int h[3];
+                (void)hipMemcpyAsync(h, c->d_counts, sizeof(h), hipMemcpyDeviceToHost, stream);
+                (void)hipStreamSynchronize(stream);
+                fprintf(stderr, "[pt] level %d: in %s, continuation %d, shadow %d\n", level,
+                        level == 0 ? "(batch)" : "(prev)", h[cur ^ 1], h[2]);
+            }
             if (level + 1 < levels) {
                 StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-                HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, qout.rays, qout.stride, qout.count,
+                HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, false, c->stack_need, gt, stream, c->sc, qout.rays, qout.stride, qout.count,
                                           0, qout.prim, qout.t, qout.b1, qout.b2, no_rs, cnt));
                 cur ^= 1;
             }

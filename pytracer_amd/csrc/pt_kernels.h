@@ -5,6 +5,7 @@
 #include "pt_device.h"
 
 #define PT_BLOCK 256   // 4 waves of 64 lanes
+#define PT_CNT_SHARDS 256
 
 enum {
     CNT_NODE_VISITS = 0,
@@ -74,9 +75,10 @@ struct RenderConst {
     const double *table;
 };
 
-hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
-                           long stride, const int *n_ptr, int n_val, int *out_prim, double *out_t, double *out_b1,
-                           double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
+hipError_t pt_launch_trace(int variant, int *next_ray, bool any, int stack, int grid, hipStream_t stream,
+                           const DScene &sc, const double *rays, long stride, const int *n_ptr, int n_val,
+                           int *out_prim, double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
+                           unsigned long long *counters);
 hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, const Queue &q,
                             const PathState &st, unsigned long long *counters);
 hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,

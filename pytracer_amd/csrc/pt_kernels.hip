@@ -94,6 +94,27 @@ __device__ __forceinline__ int traverse(const DScene &sc, Ray &r, int *stack, do
     return result;
 }
 
+// Census counters are sharded ([PT_CNT_SHARDS][CNT_COUNT], summed on the host): thousands of
+// waves adding to ONE word serialise at ~88 atomics/us (MI355X_MICROARCH.md "dequeue"), which
+// cost every launch hundreds of microseconds before sharding.  Waves that traced nothing skip.
+template <bool ANY>
+__device__ __forceinline__ void trace_count(unsigned long long *counters, unsigned nvis, unsigned ntri, unsigned nray) {
+    unsigned long long x = wave_sum_u64(nray);
+    x = __shfl(x, 0);
+    if (x == 0ull) return;
+    unsigned long long v = wave_sum_u64(nvis), w = wave_sum_u64(ntri);
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long *c = counters + (size_t)(blockIdx.x % PT_CNT_SHARDS) * CNT_COUNT;
+        atomicAdd(c + CNT_NODE_VISITS, v);
+        atomicAdd(c + CNT_TRI_TESTS, w);
+        atomicAdd(c + (ANY ? CNT_RAYS_ANY : CNT_RAYS_CLOSEST), x);
+        if (ANY) {
+            atomicAdd(c + CNT_NODE_VISITS_ANY, v);
+            atomicAdd(c + CNT_TRI_TESTS_ANY, w);
+        }
+    }
+}
+
 // rays: component-major SoA [8][stride]; outputs dense per ray.  ANY + rs.L: the shadow
 // "resolve" (K6) is fused: an unoccluded ray adds its precomputed contribution to L[slot].
 template <int STACK, bool ANY>
@@ -126,28 +147,152 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene sc, const double *__r
             unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + i]);
         }
     }
-    if (counters) {
-        unsigned long long v = wave_sum_u64(nvis), w = wave_sum_u64(ntri), x = wave_sum_u64(nray);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(counters + CNT_NODE_VISITS, v);
-            atomicAdd(counters + CNT_TRI_TESTS, w);
-            atomicAdd(counters + (ANY ? CNT_RAYS_ANY : CNT_RAYS_CLOSEST), x);
-            if (ANY) {
-                atomicAdd(counters + CNT_NODE_VISITS_ANY, v);
-                atomicAdd(counters + CNT_TRI_TESTS_ANY, w);
+    if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
+}
+
+// ---- variant 1: "while-while" with dynamic ray fetch -------------------------------------
+// Same per-ray operation sequence as traverse<> (so results stay bit-identical), but the wave
+// is re-converged around the two expensive phases: all lanes first walk interior nodes until
+// each holds a leaf (or has finished), then the leaf triangles are tested with most lanes
+// active, instead of paying the divergent triangle code on almost every node step.  A lane
+// whose ray has finished pulls the next ray index from a global counter (one wave-aggregated
+// atomic), so a wave does not idle behind its longest ray.
+template <int STACK, bool ANY>
+__global__ __launch_bounds__(PT_BLOCK) void k_trace_ww(DScene sc, const double *__restrict__ rays, long stride,
+                                                       const int *__restrict__ n_ptr, int n_val,
+                                                       int *__restrict__ out_prim, double *__restrict__ out_t,
+                                                       double *__restrict__ out_b1, double *__restrict__ out_b2,
+                                                       ShadowResolve rs, unsigned long long *counters,
+                                                       int *__restrict__ next_ray) {
+    __shared__ int s_stack[STACK * PT_BLOCK];
+    int *stack = s_stack + threadIdx.x;
+    const int n = n_ptr ? *n_ptr : n_val;
+    unsigned nvis = 0, ntri = 0, nray = 0;
+    const bool empty_scene = sc.n_nodes == 0;
+
+    bool have = false, exhausted = false;
+    int ray_i = 0;
+    Ray r;
+    double invx = 0, invy = 0, invz = 0, b1 = 0., b2 = 0.;
+    bool negx = false, negy = false, negz = false;
+    int todo_idx = 0, node_idx = 0, result = 0, leaf_off = 0, leaf_cnt = 0;
+    r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 0); r.mint = 0; r.maxt = 0;
+
+    for (;;) {
+        // ---- (re)fetch: lanes without a ray take the next indices -----------------------------
+        const unsigned long long idle = __ballot(!have && !exhausted);
+        if (idle != 0ull) {
+            const bool want = !have && !exhausted;
+            const int leader = __ffsll((long long)idle) - 1;
+            int base = 0;
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(next_ray, __popcll(idle));
+            base = __shfl(base, leader);
+            if (want) {
+                ray_i = base + (int)lane_prefix(idle);
+                if (ray_i < n) {
+                    r.o = mk3(rays[ray_i], rays[stride + ray_i], rays[2 * stride + ray_i]);
+                    r.d = mk3(rays[3 * stride + ray_i], rays[4 * stride + ray_i], rays[5 * stride + ray_i]);
+                    r.mint = rays[6 * stride + ray_i];
+                    r.maxt = rays[7 * stride + ray_i];
+                    invx = 1.0 / r.d.x; invy = 1.0 / r.d.y; invz = 1.0 / r.d.z;
+                    negx = r.d.x < 0.0; negy = r.d.y < 0.0; negz = r.d.z < 0.0;
+                    todo_idx = 0; node_idx = 0; leaf_cnt = 0;
+                    result = ANY ? 0 : -1;
+                    b1 = 0.; b2 = 0.;
+                    have = true;
+                    nray++;
+                } else {
+                    exhausted = true;
+                }
             }
         }
+        if (__ballot(have) == 0ull) break;
+        bool done = !have || empty_scene;
+        // ---- phase 1: interior walk until this lane holds a leaf or is done -----------------
+        while (!done && leaf_cnt == 0) {
+            const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node_idx);
+            double2 n0 = q[0], n1 = q[1], n2 = q[2];
+            int2 meta = *reinterpret_cast<const int2 *>(&q[3]);
+            nvis++;
+            double tmin = ((negx ? n1.y : n0.x) - r.o.x) * invx;
+            double tmax = ((negx ? n0.x : n1.y) - r.o.x) * invx;
+            double tmin_y = ((negy ? n2.x : n0.y) - r.o.y) * invy;
+            double tmax_y = ((negy ? n0.y : n2.x) - r.o.y) * invy;
+            bool hitbox = !(tmin > tmax_y || tmin_y > tmax);
+            if (tmin_y > tmin) tmin = tmin_y;
+            if (tmax_y < tmax) tmax = tmax_y;
+            double tmin_z = ((negz ? n2.y : n1.x) - r.o.z) * invz;
+            double tmax_z = ((negz ? n1.x : n2.y) - r.o.z) * invz;
+            hitbox = hitbox && !(tmin > tmax_z || tmin_z > tmax);
+            if (tmin_z > tmin) tmin = tmin_z;
+            if (tmax_z < tmax) tmax = tmax_z;
+            hitbox = hitbox && (tmin < r.maxt) && (tmax > r.mint);
+            if (hitbox) {
+                const int nprim = meta.y & 0xFFFF;
+                if (nprim > 0) {
+                    leaf_off = meta.x; leaf_cnt = nprim;
+                } else {
+                    const int axis = meta.y >> 16;
+                    const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
+                    stack[(todo_idx++) * PT_BLOCK] = neg ? node_idx + 1 : meta.x;
+                    node_idx = neg ? meta.x : node_idx + 1;
+                }
+            } else {
+                if (todo_idx == 0) done = true;
+                else node_idx = stack[(--todo_idx) * PT_BLOCK];
+            }
+        }
+        // ---- phase 2: the leaf ---------------------------------------------------------------
+        if (leaf_cnt > 0) {
+            for (int k = 0; k < leaf_cnt; k++) {
+                double t, tb1, tb2;
+                ntri++;
+                if (tri_test(sc.tris + leaf_off + k, r, t, tb1, tb2)) {
+                    if (ANY) { result = 1; done = true; break; }
+                    result = leaf_off + k;
+                    b1 = tb1; b2 = tb2;
+                    r.maxt = t;
+                }
+            }
+            leaf_cnt = 0;
+            if (!done) {
+                if (todo_idx == 0) done = true;
+                else node_idx = stack[(--todo_idx) * PT_BLOCK];
+            }
+        }
+        // ---- retire -------------------------------------------------------------------------
+        if (have && done) {
+            if (out_prim) out_prim[ray_i] = result;
+            if (!ANY) {
+                if (out_t) out_t[ray_i] = r.maxt;
+                if (out_b1) out_b1[ray_i] = b1;
+                if (out_b2) out_b2[ray_i] = b2;
+            } else if (rs.L && result == 0) {
+                const int slot = rs.slot[ray_i];
+                unsafeAtomicAdd(rs.L + slot, rs.c[ray_i]);
+                unsafeAtomicAdd(rs.L + rs.lstride + slot, rs.c[rs.cstride + ray_i]);
+                unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + ray_i]);
+            }
+            have = false;
+        }
     }
+    if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
 }
 
 template <bool ANY>
-static hipError_t launch_trace_t(int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
-                                 long stride, const int *n_ptr, int n_val, int *out_prim, double *out_t,
-                                 double *out_b1, double *out_b2, const ShadowResolve &rs,
+static hipError_t launch_trace_t(int variant, int *next_ray, int stack, int grid, hipStream_t stream, const DScene &sc,
+                                 const double *rays, long stride, const int *n_ptr, int n_val, int *out_prim,
+                                 double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
                                  unsigned long long *counters) {
-#define PT_LAUNCH(S)                                                                                      \
-    hipLaunchKernelGGL((k_trace<S, ANY>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays, stride, n_ptr, \
-                       n_val, out_prim, out_t, out_b1, out_b2, rs, counters)
+#define PT_LAUNCH(S)                                                                                          \
+    do {                                                                                                      \
+        if (variant == 1)                                                                                     \
+            hipLaunchKernelGGL((k_trace_ww<S, ANY>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays, stride, \
+                               n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, next_ray);        \
+        else                                                                                                  \
+            hipLaunchKernelGGL((k_trace<S, ANY>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays, stride,    \
+                               n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);                  \
+    } while (0)
     if (stack <= 16) PT_LAUNCH(16);
     else if (stack <= 24) PT_LAUNCH(24);
     else if (stack <= 32) PT_LAUNCH(32);
@@ -157,11 +302,16 @@ static hipError_t launch_trace_t(int stack, int grid, hipStream_t stream, const 
     return hipGetLastError();
 }
 
-hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
-                           long stride, const int *n_ptr, int n_val, int *out_prim, double *out_t, double *out_b1,
-                           double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
-    if (any) return launch_trace_t<true>(stack, grid, stream, sc, rays, stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
-    return launch_trace_t<false>(stack, grid, stream, sc, rays, stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+hipError_t pt_launch_trace(int variant, int *next_ray, bool any, int stack, int grid, hipStream_t stream,
+                           const DScene &sc, const double *rays, long stride, const int *n_ptr, int n_val,
+                           int *out_prim, double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
+                           unsigned long long *counters) {
+    if (variant == 1) {   // the dynamic ray counter starts at 0 for every launch
+        hipError_t e = hipMemsetAsync(next_ray, 0, sizeof(int), stream);
+        if (e != hipSuccess) return e;
+    }
+    if (any) return launch_trace_t<true>(variant, next_ray, stack, grid, stream, sc, rays, stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    return launch_trace_t<false>(variant, next_ray, stack, grid, stream, sc, rays, stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
 }
 
 // =========================================================================================
@@ -293,7 +443,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
     st.img[i] = ix; st.img[P + i] = iy;
     if (counters && threadIdx.x == 0) {
         int cnt = nb - blockIdx.x * PT_BLOCK;
-        atomicAdd(counters + CNT_CAMERA_SAMPLES, (unsigned long long)(cnt > PT_BLOCK ? PT_BLOCK : cnt));
+        atomicAdd(counters + (size_t)(blockIdx.x % PT_CNT_SHARDS) * CNT_COUNT + CNT_CAMERA_SAMPLES,
+                  (unsigned long long)(cnt > PT_BLOCK ? PT_BLOCK : cnt));
     }
 }
 
@@ -345,8 +496,11 @@ __device__ __forceinline__ void push_shadow(const ShadowQueue &sh, bool pred, co
 //   Σ light.le on a miss, renderer/renderer.py:58-75).  `level` = ray.depth.
 // KIND 1: PathIntegrator.li AS IT EXECUTES (integrator/surface/path.py:44-144; `specular_bounce`
 //   always True after the first sample_f, Q4).  `level` = bounce_cnt.
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 2
+#endif
 template <int KIND>
-__global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
+__global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
                                                     int level, Queue qin, Queue qout, ShadowQueue sh, PathState st) {
     const RenderConst &rc = *rcp;
     const int n = *qin.count;
@@ -511,16 +665,16 @@ hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene 
 
 __device__ __forceinline__ d3 guarded_radiance(d3 L, unsigned long long *counters) {
     if (isnan(L.x) || isnan(L.y) || isnan(L.z)) {
-        if (counters) atomicAdd(counters + CNT_GUARD_NAN, 1ull);
+        if (counters) atomicAdd(counters + (size_t)(blockIdx.x % PT_CNT_SHARDS) * CNT_COUNT + CNT_GUARD_NAN, 1ull);
         return mk3(0, 0, 0);
     }
     const double y = spec_y(L);
     if (y < -PT_EPS) {
-        if (counters) atomicAdd(counters + CNT_GUARD_NEG, 1ull);
+        if (counters) atomicAdd(counters + (size_t)(blockIdx.x % PT_CNT_SHARDS) * CNT_COUNT + CNT_GUARD_NEG, 1ull);
         return mk3(0, 0, 0);
     }
     if (y == __builtin_inf()) {
-        if (counters) atomicAdd(counters + CNT_GUARD_INF, 1ull);
+        if (counters) atomicAdd(counters + (size_t)(blockIdx.x % PT_CNT_SHARDS) * CNT_COUNT + CNT_GUARD_INF, 1ull);
         return mk3(0, 0, 0);
     }
     return L;
