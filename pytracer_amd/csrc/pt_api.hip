@@ -30,6 +30,7 @@ struct pt_ctx {
     ShadowQueue sh;
     PathState st;
     int *d_counts;           // [4]: q0, q1, shadow, next-ray counter of the dynamic-fetch trace kernel
+    int trace_occ[2];        // resident blocks/CU of the closest / any trace kernels (0 = not queried)
     int trace_variant;       // 0: per-ray loop, 1: while-while + dynamic fetch (PT_TRACE_VARIANT)
     RenderConst *d_rc;
     unsigned long long *d_counters;
@@ -292,15 +293,23 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     s.n_nodes = d->n_nodes; s.n_tris = d->n_tris; s.n_mats = d->n_materials; s.n_lights = d->n_lights;
     memcpy(s.le_sum, le, sizeof(le));
     c->stack_need = std::max(depth, 1);
+    c->trace_occ[0] = c->trace_occ[1] = 0;
     c->has_spec_reflect = spec;
     c->shadow_per_vertex_direct = spv;
     c->have_scene = true;
     return PT_OK;
 }
 
-static int trace_grid(const pt_ctx *c, long n) {
+// Grid of a trace launch: one full residency round (CUs x resident workgroups of that kernel),
+// grid-stride inside.  A grid that is not a multiple of the residency leaves a partial second
+// round: 2048 blocks on a 1280-block residency cost 14-17 % (scripts/trace_micro.py).
+static int trace_grid(pt_ctx *c, long n, bool any) {
     long blocks = (n + PT_BLOCK - 1) / PT_BLOCK;
-    long cap = (long)c->n_cu * 8;
+    int &occ = c->trace_occ[any ? 1 : 0];
+    if (occ == 0) occ = pt_trace_occupancy(c->trace_variant, any, c->stack_need);
+    long per_cu = occ;
+    if (const char *e = getenv("PT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1l, atol(e));
+    long cap = (long)c->n_cu * per_cu;
     return (int)std::max<long>(1, std::min(blocks, cap));
 }
 
@@ -345,7 +354,7 @@ extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hi
     c->ev_used = 0;
     {
         StageTimer tm(c, stream, any_hit ? STAGE_TRACE_ANY : STAGE_TRACE_CLOSEST);
-        HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, any_hit != 0, c->stack_need, trace_grid(c, n), stream, c->sc, rays, (long)n, nullptr,
+        HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, any_hit != 0, c->stack_need, trace_grid(c, n, any_hit != 0), stream, c->sc, rays, (long)n, nullptr,
                                   (int)n, prim, t, b1, b2, rs, cnt));
     }
     if (stats) return read_counters(c, stream, stats);
@@ -484,7 +493,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     for (long base = 0; base < total; base += batch) {
         const int nb = (int)std::min(batch, total - base);
         const int g = (nb + PT_BLOCK - 1) / PT_BLOCK;
-        const int gt = trace_grid(c, nb);
+        const int gt = trace_grid(c, nb, false), gta = trace_grid(c, nb, true);
+        const int gs = (int)std::max<long>(1, std::min<long>((nb + PT_BLOCK - 1) / PT_BLOCK, (long)c->n_cu * 4));
         {
             StageTimer tm(c, stream, STAGE_RAYGEN);
             HIPCHK(c, pt_launch_raygen(g, stream, c->d_rc, base, nb, c->q[0], c->st, cnt));
@@ -492,7 +502,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         HIPCHK(c, pt_launch_set_int(stream, c->q[0].count, nb));
         if (ig->pretest) {   // renderer.py:168: same hit flag as the closest-hit pass below
             StageTimer tm(c, stream, STAGE_TRACE_ANY);
-            HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, true, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
+            HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, true, c->stack_need, gta, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
                                       nb, nullptr, nullptr, nullptr, nullptr, no_rs, cnt));
         }
         {
@@ -507,12 +517,12 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             HIPCHK(c, hipMemsetAsync(c->sh.count, 0, sizeof(int), stream));
             {
                 StageTimer tm(c, stream, STAGE_SHADE);
-                HIPCHK(c, pt_launch_shade(ig->kind, gt, stream, c->sc, c->d_rc, base, level, qin, qout, c->sh, c->st));
+                HIPCHK(c, pt_launch_shade(ig->kind, gs, stream, c->sc, c->d_rc, base, level, qin, qout, c->sh, c->st));
             }
             ShadowResolve rs = {c->sh.c, c->sh.stride, c->sh.slot, c->st.L, c->st.stride};
             {
                 StageTimer tm(c, stream, STAGE_TRACE_ANY);
-                HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, true, c->stack_need, trace_grid(c, (long)nb * spv), stream, c->sc,
+                HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, true, c->stack_need, trace_grid(c, (long)nb * spv, true), stream, c->sc,
                                           c->sh.rays, c->sh.stride, c->sh.count, 0, nullptr, nullptr, nullptr, nullptr,
                                           rs, cnt));
             }

@@ -117,8 +117,11 @@ __device__ __forceinline__ void trace_count(unsigned long long *counters, unsign
 
 // rays: component-major SoA [8][stride]; outputs dense per ray.  ANY + rs.L: the shadow
 // "resolve" (K6) is fused: an unoccluded ray adds its precomputed contribution to L[slot].
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 6   // <= 80 VGPRs: 6 waves/SIMD, the same residency the 24-entry LDS stack allows
+#endif
 template <int STACK, bool ANY>
-__global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene sc, const double *__restrict__ rays, long stride,
+__global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, const double *__restrict__ rays, long stride,
                                                     const int *__restrict__ n_ptr, int n_val,
                                                     int *__restrict__ out_prim, double *__restrict__ out_t,
                                                     double *__restrict__ out_b1, double *__restrict__ out_b2,
@@ -300,6 +303,28 @@ static hipError_t launch_trace_t(int variant, int *next_ray, int stack, int grid
     else PT_LAUNCH(64);
 #undef PT_LAUNCH
     return hipGetLastError();
+}
+
+// Resident workgroups per CU of the trace kernel that pt_launch_trace would pick (advisory
+// occupancy API; used only to size the grid to one full residency round, never for correctness).
+template <bool ANY>
+static int trace_occupancy_t(int variant, int stack) {
+    int nb = 0;
+#define PT_OCC(S)                                                                                              \
+    do {                                                                                                       \
+        if (variant == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_ww<S, ANY>, PT_BLOCK, 0); \
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<S, ANY>, PT_BLOCK, 0);            \
+    } while (0)
+    if (stack <= 16) PT_OCC(16);
+    else if (stack <= 24) PT_OCC(24);
+    else if (stack <= 32) PT_OCC(32);
+    else if (stack <= 48) PT_OCC(48);
+    else PT_OCC(64);
+#undef PT_OCC
+    return nb > 0 ? nb : 4;
+}
+int pt_trace_occupancy(int variant, bool any, int stack) {
+    return any ? trace_occupancy_t<true>(variant, stack) : trace_occupancy_t<false>(variant, stack);
 }
 
 hipError_t pt_launch_trace(int variant, int *next_ray, bool any, int stack, int grid, hipStream_t stream,
