@@ -29,7 +29,7 @@ struct pt_ctx {
     Queue q[2];
     ShadowQueue sh;
     PathState st;
-    int *d_counts;           // [4]: q0, q1, shadow, next-ray counter of the dynamic-fetch trace kernel
+    int *d_counts;           // [3+8]: q0, q1, shadow, then the 8 sharded next-ray counters of the dynamic trace kernel
     int trace_occ[2];        // resident blocks/CU of the closest / any trace kernels (0 = not queried)
     int trace_variant;       // 0: per-ray loop, 1: while-while + dynamic fetch (PT_TRACE_VARIANT)
     RenderConst *d_rc;
@@ -94,7 +94,7 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    CREATE_CHK(hipMalloc((void **)&c->d_counts, 4 * sizeof(int)));
+    CREATE_CHK(hipMalloc((void **)&c->d_counts, 16 * sizeof(int)));
     c->trace_variant = 0;
     if (const char *e = getenv("PT_TRACE_VARIANT")) c->trace_variant = atoi(e);
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
@@ -354,8 +354,8 @@ extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hi
     c->ev_used = 0;
     {
         StageTimer tm(c, stream, any_hit ? STAGE_TRACE_ANY : STAGE_TRACE_CLOSEST);
-        HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, any_hit != 0, c->stack_need, trace_grid(c, n, any_hit != 0), stream, c->sc, rays, (long)n, nullptr,
-                                  (int)n, prim, t, b1, b2, rs, cnt));
+        HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 4, any_hit != 0, c->stack_need, trace_grid(c, n, any_hit != 0), stream, c->sc, rays, (long)n, nullptr,
+                                  (int)n, prim, t, b1, b2, rs, cnt, (long)n));
     }
     if (stats) return read_counters(c, stream, stats);
     return PT_OK;
@@ -502,13 +502,13 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         HIPCHK(c, pt_launch_set_int(stream, c->q[0].count, nb));
         if (ig->pretest) {   // renderer.py:168: same hit flag as the closest-hit pass below
             StageTimer tm(c, stream, STAGE_TRACE_ANY);
-            HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, true, c->stack_need, gta, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
-                                      nb, nullptr, nullptr, nullptr, nullptr, no_rs, cnt));
+            HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 4, true, c->stack_need, gta, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
+                                      nb, nullptr, nullptr, nullptr, nullptr, no_rs, cnt, (long)nb));
         }
         {
             StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-            HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, false, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
-                                      nb, c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
+            HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 4, false, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
+                                      nb, c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt, (long)nb));
         }
         int cur = 0;
         for (int level = 0; level < levels; level++) {
@@ -522,9 +522,9 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             ShadowResolve rs = {c->sh.c, c->sh.stride, c->sh.slot, c->st.L, c->st.stride};
             {
                 StageTimer tm(c, stream, STAGE_TRACE_ANY);
-                HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, true, c->stack_need, trace_grid(c, (long)nb * spv, true), stream, c->sc,
+                HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 4, true, c->stack_need, trace_grid(c, (long)nb * spv, true), stream, c->sc,
                                           c->sh.rays, c->sh.stride, c->sh.count, 0, nullptr, nullptr, nullptr, nullptr,
-                                          rs, cnt));
+                                          rs, cnt, (long)nb * spv));
             }
             if (getenv("PT_DEBUG_LEVELS") && base == 0) {   // debugging aid: queue sizes per level (syncs)
                 int h[3];
@@ -535,8 +535,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             }
             if (level + 1 < levels) {
                 StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-                HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 3, false, c->stack_need, gt, stream, c->sc, qout.rays, qout.stride, qout.count,
-                                          0, qout.prim, qout.t, qout.b1, qout.b2, no_rs, cnt));
+                HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 4, false, c->stack_need, gt, stream, c->sc, qout.rays, qout.stride, qout.count,
+                                          0, qout.prim, qout.t, qout.b1, qout.b2, no_rs, cnt, (long)nb));
                 cur ^= 1;
             }
         }

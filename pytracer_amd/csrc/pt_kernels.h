@@ -78,7 +78,7 @@ struct RenderConst {
 hipError_t pt_launch_trace(int variant, int *next_ray, bool any, int stack, int grid, hipStream_t stream,
                            const DScene &sc, const double *rays, long stride, const int *n_ptr, int n_val,
                            int *out_prim, double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
-                           unsigned long long *counters);
+                           unsigned long long *counters, long n_bound);
 int pt_trace_occupancy(int variant, bool any, int stack);
 hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, const Queue &q,
                             const PathState &st, unsigned long long *counters);
