@@ -29,9 +29,8 @@ struct pt_ctx {
     Queue q[2];
     ShadowQueue sh;
     PathState st;
-    int *d_counts;           // [3+8]: q0, q1, shadow, then the 8 sharded next-ray counters of the dynamic trace kernel
+    int *d_counts;           // [3][PT_SEG]: region fill counters of q0, q1 and the shadow queue
     int trace_occ[2];        // resident blocks/CU of the closest / any trace kernels (0 = not queried)
-    int trace_variant;       // 0: per-ray loop, 1: while-while + dynamic fetch (PT_TRACE_VARIANT)
     RenderConst *d_rc;
     unsigned long long *d_counters;
     int n_cu;
@@ -94,9 +93,7 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    CREATE_CHK(hipMalloc((void **)&c->d_counts, 16 * sizeof(int)));
-    c->trace_variant = 0;
-    if (const char *e = getenv("PT_TRACE_VARIANT")) c->trace_variant = atoi(e);
+    CREATE_CHK(hipMalloc((void **)&c->d_counts, 3 * PT_SEG * sizeof(int)));
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
     CREATE_CHK(hipMalloc((void **)&c->d_counters, PT_CNT_SHARDS * CNT_COUNT * sizeof(unsigned long long)));
     c->ev = new std::vector<hipEvent_t>();
@@ -306,7 +303,7 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
 static int trace_grid(pt_ctx *c, long n, bool any) {
     long blocks = (n + PT_BLOCK - 1) / PT_BLOCK;
     int &occ = c->trace_occ[any ? 1 : 0];
-    if (occ == 0) occ = pt_trace_occupancy(c->trace_variant, any, c->stack_need);
+    if (occ == 0) occ = pt_trace_occupancy(any, c->stack_need);
     long per_cu = occ;
     if (const char *e = getenv("PT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1l, atol(e));
     long cap = (long)c->n_cu * per_cu;
@@ -354,8 +351,8 @@ extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hi
     c->ev_used = 0;
     {
         StageTimer tm(c, stream, any_hit ? STAGE_TRACE_ANY : STAGE_TRACE_CLOSEST);
-        HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 4, any_hit != 0, c->stack_need, trace_grid(c, n, any_hit != 0), stream, c->sc, rays, (long)n, nullptr,
-                                  (int)n, prim, t, b1, b2, rs, cnt, (long)n));
+        HIPCHK(c, pt_launch_trace(any_hit != 0, c->stack_need, trace_grid(c, n, any_hit != 0), stream, c->sc, rays,
+                                  (long)n, nullptr, 0, (int)n, prim, t, b1, b2, rs, cnt));
     }
     if (stats) return read_counters(c, stream, stats);
     return PT_OK;
@@ -363,9 +360,12 @@ extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hi
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// carve the wavefront workspace: two ray queues, the shadow queue and the path state
-static int ensure_workspace(pt_ctx *c, long cap, long sh_cap) {
-    if (c->ws && c->cap >= cap && c->sh_cap >= sh_cap) return PT_OK;
+// carve the wavefront workspace: two ray queues, the shadow queue (all segmented, pt_kernels.h)
+// and the path state.  `paths` = paths in flight, spv = shadow rays one shaded entry can emit.
+static int ensure_workspace(pt_ctx *c, long paths, int spv) {
+    const long seg = 64 * ((((paths + 63) / 64) + PT_SEG - 1) / PT_SEG);   // whole 64-entry chunks per region
+    const long cap = seg * PT_SEG, sh_cap = cap * spv;
+    if (c->ws && c->cap == cap && c->sh_cap == sh_cap) return PT_OK;
     if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; }
     size_t bytes = 0;
     auto need = [&](size_t b) { size_t off = bytes; bytes += align_up(b); return off; };
@@ -386,13 +386,13 @@ static int ensure_workspace(pt_ctx *c, long cap, long sh_cap) {
     char *b = (char *)c->ws;
     for (int k = 0; k < 2; k++) {
         Queue &q = c->q[k];
-        q.rays = (double *)(b + off_q[k][0]); q.stride = cap;
+        q.rays = (double *)(b + off_q[k][0]); q.stride = cap; q.seg = seg;
         q.slot = (int *)(b + off_q[k][1]); q.prim = (int *)(b + off_q[k][2]);
         q.t = (double *)(b + off_q[k][3]); q.b1 = (double *)(b + off_q[k][4]); q.b2 = (double *)(b + off_q[k][5]);
-        q.count = c->d_counts + k;
+        q.count = c->d_counts + k * PT_SEG;
     }
     c->sh.rays = (double *)(b + off_sr); c->sh.c = (double *)(b + off_sc); c->sh.slot = (int *)(b + off_ss);
-    c->sh.stride = sh_cap; c->sh.count = c->d_counts + 2;
+    c->sh.stride = sh_cap; c->sh.seg = seg * spv; c->sh.count = c->d_counts + 2 * PT_SEG;
     c->st.T = (double *)(b + off_T); c->st.L = (double *)(b + off_L); c->st.img = (double *)(b + off_img);
     c->st.stride = cap;
     c->cap = cap; c->sh_cap = sh_cap; c->ws_bytes = bytes;
@@ -473,7 +473,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     batch = std::min(batch, total);
     batch = (batch + 63) & ~63l;
     const int spv = ig->kind == PT_INTEG_DIRECT ? std::max(c->shadow_per_vertex_direct, 1) : 1;
-    int rc = ensure_workspace(c, batch, batch * spv);
+    int rc = ensure_workspace(c, batch, spv);
     if (rc != PT_OK) return rc;
 
     HIPCHK(c, hipMemcpyAsync(c->d_rc, &h, sizeof(h), hipMemcpyHostToDevice, stream));
@@ -499,22 +499,22 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             StageTimer tm(c, stream, STAGE_RAYGEN);
             HIPCHK(c, pt_launch_raygen(g, stream, c->d_rc, base, nb, c->q[0], c->st, cnt));
         }
-        HIPCHK(c, pt_launch_set_int(stream, c->q[0].count, nb));
         if (ig->pretest) {   // renderer.py:168: same hit flag as the closest-hit pass below
             StageTimer tm(c, stream, STAGE_TRACE_ANY);
-            HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 4, true, c->stack_need, gta, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
-                                      nb, nullptr, nullptr, nullptr, nullptr, no_rs, cnt, (long)nb));
+            HIPCHK(c, pt_launch_trace(true, c->stack_need, gta, stream, c->sc, c->q[0].rays, c->q[0].stride,
+                                      c->q[0].count, c->q[0].seg, 0, nullptr, nullptr, nullptr, nullptr, no_rs, cnt));
         }
         {
             StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-            HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 4, false, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride, nullptr,
-                                      nb, c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt, (long)nb));
+            HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride,
+                                      c->q[0].count, c->q[0].seg, 0, c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2,
+                                      no_rs, cnt));
         }
         int cur = 0;
         for (int level = 0; level < levels; level++) {
             Queue &qin = c->q[cur], &qout = c->q[cur ^ 1];
-            HIPCHK(c, hipMemsetAsync(qout.count, 0, sizeof(int), stream));
-            HIPCHK(c, hipMemsetAsync(c->sh.count, 0, sizeof(int), stream));
+            HIPCHK(c, hipMemsetAsync(qout.count, 0, PT_SEG * sizeof(int), stream));
+            HIPCHK(c, hipMemsetAsync(c->sh.count, 0, PT_SEG * sizeof(int), stream));
             {
                 StageTimer tm(c, stream, STAGE_SHADE);
                 HIPCHK(c, pt_launch_shade(ig->kind, gs, stream, c->sc, c->d_rc, base, level, qin, qout, c->sh, c->st));
@@ -522,21 +522,23 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             ShadowResolve rs = {c->sh.c, c->sh.stride, c->sh.slot, c->st.L, c->st.stride};
             {
                 StageTimer tm(c, stream, STAGE_TRACE_ANY);
-                HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 4, true, c->stack_need, trace_grid(c, (long)nb * spv, true), stream, c->sc,
-                                          c->sh.rays, c->sh.stride, c->sh.count, 0, nullptr, nullptr, nullptr, nullptr,
-                                          rs, cnt, (long)nb * spv));
+                HIPCHK(c, pt_launch_trace(true, c->stack_need, trace_grid(c, (long)nb * spv, true), stream, c->sc,
+                                          c->sh.rays, c->sh.stride, c->sh.count, c->sh.seg, 0, nullptr, nullptr,
+                                          nullptr, nullptr, rs, cnt));
             }
             if (getenv("PT_DEBUG_LEVELS") && base == 0) {   // debugging aid: queue sizes per level (syncs)
-                int h[3];
+                int h[3 * PT_SEG];
+                long tot[3] = {0, 0, 0};
                 (void)hipMemcpyAsync(h, c->d_counts, sizeof(h), hipMemcpyDeviceToHost, stream);
                 (void)hipStreamSynchronize(stream);
-                fprintf(stderr, "[pt] level %d: in %s, continuation %d, shadow %d\n", level,
-                        level == 0 ? "(batch)" : "(prev)", h[cur ^ 1], h[2]);
+                for (int k = 0; k < 3 * PT_SEG; k++) tot[k / PT_SEG] += h[k];
+                fprintf(stderr, "[pt] level %d: in %ld, continuation %ld, shadow %ld\n", level, tot[cur], tot[cur ^ 1],
+                        tot[2]);
             }
             if (level + 1 < levels) {
                 StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-                HIPCHK(c, pt_launch_trace(c->trace_variant, c->d_counts + 4, false, c->stack_need, gt, stream, c->sc, qout.rays, qout.stride, qout.count,
-                                          0, qout.prim, qout.t, qout.b1, qout.b2, no_rs, cnt, (long)nb));
+                HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, qout.rays, qout.stride, qout.count,
+                                          qout.seg, 0, qout.prim, qout.t, qout.b1, qout.b2, no_rs, cnt));
                 cur ^= 1;
             }
         }

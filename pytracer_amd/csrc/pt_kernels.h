@@ -21,24 +21,38 @@ enum {
     CNT_COUNT
 };
 
-// dense ray queue: traced rays and (after K3) their hit records, plus the path slot they belong to
+// Segmented queues.  A render queue of capacity `stride` is PT_SEG regions of `seg` entries
+// (stride = PT_SEG * seg), each with its own fill counter; entry k of region r is element
+// r*seg + k of every array.  Region r is a private lane through the pipeline: the waves with
+// (global wave id) % PT_SEG == r read region r of the input queue and append to region r of the
+// output queues, so a region never receives more entries than its input region held (x the
+// shadow rays per entry) and cannot overflow, and one counter sees 1/PT_SEG of the appends.
+// With ONE counter per queue the ~1 M wave-level appends of a 64 M-sample level serialised on
+// one L2 word (~88 atomics/us, MI355X_MICROARCH.md) and cost more than the shading itself.
+// Grids of kernels that walk a segmented queue are multiples of PT_SEG_BLOCKS workgroups.
+#define PT_SEG 64
+#define PT_SEG_BLOCKS (PT_SEG / (PT_BLOCK / 64))
+
+// ray queue: traced rays and (after K3) their hit records, plus the path slot they belong to
 struct Queue {
     double *rays;   // [8][stride]: ox,oy,oz,dx,dy,dz,mint,maxt
     long stride;
+    long seg;       // region size, a multiple of 64
     int *slot;      // [stride]
     int *prim;      // [stride] closest-hit primitive or -1
     double *t;      // [stride] ray.maxt after traversal
     double *b1, *b2;
-    int *count;     // device counter
+    int *count;     // [PT_SEG] device counters
 };
 
-// dense shadow-ray queue with the contribution each ray carries if unoccluded
+// shadow-ray queue (segmented the same way) with the contribution each ray carries if unoccluded
 struct ShadowQueue {
     double *rays;   // [8][stride]
     double *c;      // [3][stride]
     long stride;
+    long seg;       // = shadow rays per entry x Queue::seg
     int *slot;
-    int *count;
+    int *count;     // [PT_SEG]
 };
 
 struct ShadowResolve {
@@ -75,11 +89,11 @@ struct RenderConst {
     const double *table;
 };
 
-hipError_t pt_launch_trace(int variant, int *next_ray, bool any, int stack, int grid, hipStream_t stream,
-                           const DScene &sc, const double *rays, long stride, const int *n_ptr, int n_val,
-                           int *out_prim, double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
-                           unsigned long long *counters, long n_bound);
-int pt_trace_occupancy(int variant, bool any, int stack);
+// seg_counts != nullptr: segmented input (regions of `seg` entries); else dense rays [0, n_val)
+hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                           long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
+                           double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
+int pt_trace_occupancy(bool any, int stack);
 hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, const Queue &q,
                             const PathState &st, unsigned long long *counters);
 hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,
@@ -89,4 +103,3 @@ hipError_t pt_launch_splat(hipStream_t stream, const RenderConst *rc, const pt_t
                            long base, int nb, const PathState &st, double *film, double *sample_L,
                            unsigned long long *counters);
 hipError_t pt_launch_film_resolve(hipStream_t stream, const double *acc, long npix, double *rgb);
-hipError_t pt_launch_set_int(hipStream_t stream, int *p, int v);

@@ -11,18 +11,6 @@
 // stack[level][thread] so that lane l always hits bank l (conflict-free ds_read/write_b32).
 // =========================================================================================
 
-// Loads through the constant address space: with a wave-uniform address the compiler emits
-// s_load (scalar data cache, read only) instead of a 64-lane vector load through the TA.
-typedef double d2v __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(4))) d2v *cptr_d2;
-__device__ __forceinline__ cptr_d2 as_const(const void *p) {
-    return (cptr_d2)(unsigned long long)p;
-}
-__device__ __forceinline__ double2 cload(cptr_d2 q, int i) {
-    const d2v v = q[i];
-    return make_double2(v.x, v.y);
-}
-
 // Triangle.intersect / intersect_p up to the range test (shape/triangle.py:173-207,245-279)
 __device__ __forceinline__ bool tri_math(double2 a0, double2 a1, double2 a2, double2 a3, double2 a4, const Ray &r,
                                          double &t_out, double &b1_out, double &b2_out) {
@@ -46,21 +34,10 @@ __device__ __forceinline__ bool tri_test(const GTri *tp, const Ray &r, double &t
     const double2 *q = reinterpret_cast<const double2 *>(tp);
     return tri_math(q[0], q[1], q[2], q[3], q[4], r, t_out, b1_out, b2_out);
 }
-// same, for a triangle index that is identical in every active lane of the wave
-__device__ __forceinline__ bool tri_test_uniform(const GTri *tp, const Ray &r, double &t_out, double &b1_out,
-                                                 double &b2_out) {
-    cptr_d2 q = as_const(tp);
-    return tri_math(cload(q, 0), cload(q, 1), cload(q, 2), cload(q, 3), cload(q, 4), r, t_out, b1_out, b2_out);
-}
-
 // BVH.intersect (bvh.py:322-365) / BVH.intersect_p (:367-410) with BVH._intersect_p (:295-320).
 // Returns the primitive index (closest; -1 = miss) or 0/1 (any hit).  r.maxt is shrunk by
 // every accepted closest hit (aggregate/primitive.py:107).
-// UNI: when every active lane of the wave is at the same node (camera waves hold the 64 samples of
-// one pixel; shadow rays converge on one light), the node / triangle record is fetched ONCE with
-// scalar loads.  PMC: the TA was 51-63 % busy issuing 4 vector loads per node step, each costing
-// 16 TA cycles even when all 64 lanes read the same 16 bytes.
-template <bool ANY, bool UNI>
+template <bool ANY>
 __device__ __forceinline__ int traverse(const DScene &sc, Ray &r, int *stack, double &b1o, double &b2o,
                                         unsigned &nvis, unsigned &ntri) {
     int result = ANY ? 0 : -1;
@@ -69,29 +46,9 @@ __device__ __forceinline__ int traverse(const DScene &sc, Ray &r, int *stack, do
     const bool negx = r.d.x < 0.0, negy = r.d.y < 0.0, negz = r.d.z < 0.0;
     int todo_idx = 0, node_idx = 0;
     for (;;) {
-        double2 n0, n1, n2;   // bmin.xy | bmin.z bmax.x | bmax.yz
-        int2 meta;
-        bool uni = false;
-        if (UNI) {
-            const int u_idx = __builtin_amdgcn_readfirstlane(node_idx);
-            uni = __all(node_idx == u_idx);
-            if (uni) {
-                cptr_d2 q = as_const(sc.nodes + u_idx);
-                n0 = cload(q, 0); n1 = cload(q, 1); n2 = cload(q, 2);
-                const double2 m = cload(q, 3);
-                meta.x = __double2loint(m.x); meta.y = __double2hiint(m.x);
-            }
-        }
-        if (!uni) {
-            const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node_idx);
-#if defined(PT_ABL_HALFLOAD)   // ablation only (wrong results): 2 of the 4 node loads
-            n0 = q[0]; n1 = n0; n2 = n0;
-            meta = *reinterpret_cast<const int2 *>(&q[3]);
-#else
-            n0 = q[0]; n1 = q[1]; n2 = q[2];
-            meta = *reinterpret_cast<const int2 *>(&q[3]);
-#endif
-        }
+        const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node_idx);
+        const double2 n0 = q[0], n1 = q[1], n2 = q[2];   // bmin.xy | bmin.z bmax.x | bmax.yz
+        const int2 meta = *reinterpret_cast<const int2 *>(&q[3]);
         nvis++;
         double tmin = ((negx ? n1.y : n0.x) - r.o.x) * invx;
         double tmax = ((negx ? n0.x : n1.y) - r.o.x) * invx;
@@ -116,13 +73,7 @@ __device__ __forceinline__ int traverse(const DScene &sc, Ray &r, int *stack, do
                 for (int i = 0; i < nprim; i++) {
                     double t, b1, b2;
                     ntri++;
-#if defined(PT_ABL_NOTRI)      // ablation only (wrong results): no triangle test
-                    const bool th = false; t = b1 = b2 = 0;
-#else
-                    const bool th = (UNI && uni) ? tri_test_uniform(sc.tris + meta.x + i, r, t, b1, b2)
-                                                 : tri_test(sc.tris + meta.x + i, r, t, b1, b2);
-#endif
-                    if (th) {
+                    if (tri_test(sc.tris + meta.x + i, r, t, b1, b2)) {
                         if (ANY) return 1;
                         result = meta.x + i;
                         b1o = b1; b2o = b2;
@@ -166,169 +117,13 @@ __device__ __forceinline__ void trace_count(unsigned long long *counters, unsign
     }
 }
 
-// rays: component-major SoA [8][stride]; outputs dense per ray.  ANY + rs.L: the shadow
-// "resolve" (K6) is fused: an unoccluded ray adds its precomputed contribution to L[slot].
+// rays: component-major SoA [8][stride]; outputs per ray at the ray's own index.  ANY + rs.L:
+// the shadow "resolve" (K6) is fused: an unoccluded ray adds its precomputed contribution to
+// L[slot].
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 6   // <= 80 VGPRs: 6 waves/SIMD, the same residency the 24-entry LDS stack allows
 #endif
-template <bool ANY, int VAR>
-__device__ __forceinline__ void trace_one(const DScene &sc, const double *__restrict__ rays, long stride, long i,
-                                          int *stack, int *__restrict__ out_prim, double *__restrict__ out_t,
-                                          double *__restrict__ out_b1, double *__restrict__ out_b2,
-                                          const ShadowResolve &rs, unsigned &nvis, unsigned &ntri);
-
-// VAR 0: static grid-stride assignment of rays to lanes.
-// VAR 4: dynamic assignment of CHUNKS of consecutive rays to waves (default).  A wave always
-//   holds 64 consecutive rays (the samples of one pixel neighbourhood: coherent walks), but which
-//   chunk it takes next comes from one of 8 sharded atomic counters, so waves that drew cheap
-//   rays take more chunks.  The static stride was a multiple of the image row length: every
-//   thread stayed in ONE image column and waves over the head ran 2x longer than the mean
-//   (PMC: 3.2 of 6 resident waves/SIMD on average).
-template <int STACK, bool ANY, int VAR>
-__global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, const double *__restrict__ rays, long stride,
-                                                    const int *__restrict__ n_ptr, int n_val,
-                                                    int *__restrict__ out_prim, double *__restrict__ out_t,
-                                                    double *__restrict__ out_b1, double *__restrict__ out_b2,
-                                                    ShadowResolve rs, unsigned long long *counters,
-                                                    int *__restrict__ next_ray, int chunk) {
-    __shared__ int s_stack[STACK * PT_BLOCK];
-    const int n = n_ptr ? *n_ptr : n_val;
-    unsigned nvis = 0, ntri = 0, nray = 0;
-    if (VAR == 4) {
-        const int lane = threadIdx.x & 63;
-        const int wave = (int)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6);
-        const long per_shard = (((long)n + 8l * chunk - 1) / (8l * chunk)) * chunk;
-        for (int k = 0; k < 8; k++) {
-            const int s = (wave + k) & 7;
-            const long s_begin = s * per_shard;
-            const long s_end = s_begin + per_shard < (long)n ? s_begin + per_shard : (long)n;
-            if (s_begin >= s_end) continue;
-            int nxt = 0;
-            if (lane == 0) nxt = atomicAdd(next_ray + s, chunk);
-            for (;;) {
-                const long c0 = s_begin + __builtin_amdgcn_readfirstlane(nxt);
-                if (c0 >= s_end) break;
-                // request the following chunk now; its round trip overlaps this chunk's traversal
-                if (lane == 0) nxt = atomicAdd(next_ray + s, chunk);
-                const long c1 = c0 + chunk < s_end ? c0 + chunk : s_end;
-                for (long i = c0 + lane; i < c1; i += 64) {
-                    trace_one<ANY, 0>(sc, rays, stride, i, s_stack + threadIdx.x, out_prim, out_t, out_b1, out_b2, rs,
-                                      nvis, ntri);
-                    nray++;
-                }
-            }
-        }
-    } else if (VAR == 5) {
-        // static assignment of 64-ray chunks to waves through a multiplicative permutation of the
-        // chunk index (chunk = prime coprime with the chunk count, chosen on the host): consecutive
-        // chunks of a wave land in unrelated image regions, without any atomic
-        const int lane = threadIdx.x & 63;
-        const long wave = (long)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6);
-        const long waves = (long)gridDim.x * (PT_BLOCK / 64);
-        const long nch = ((long)n + 63) >> 6;
-        long P = chunk;
-        while (nch % P == 0) P += 2;
-        for (long c = wave; c < nch; c += waves) {
-            const long m = (long)(((unsigned long long)c * (unsigned long long)P) % (unsigned long long)nch);
-            const long i = m * 64 + lane;
-            if (i < n) {
-                trace_one<ANY, 0>(sc, rays, stride, i, s_stack + threadIdx.x, out_prim, out_t, out_b1, out_b2, rs, nvis,
-                                  ntri);
-                nray++;
-            }
-        }
-    } else {
-        for (long i = (long)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * PT_BLOCK) {
-            trace_one<ANY, VAR>(sc, rays, stride, i, s_stack + threadIdx.x, out_prim, out_t, out_b1, out_b2, rs, nvis,
-                                ntri);
-            nray++;
-        }
-    }
-    if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
-}
-
-// ---- variant 2: software-pipelined node fetch --------------------------------------------
-// Same operation sequence per ray as traverse<> (bit-identical results and visit counts), but
-// the two possible successors of the current node — its near child, and the node on top of the
-// todo stack — are requested BEFORE the slab test of the current node, so the dependent
-// L1/L2 round trip of the next visit overlaps the f64 slab arithmetic of this one.  PMC showed
-// the plain loop parked in s_waitcnt 65 % of its wave cycles.  The stack top lives in a
-// register (LDS holds the rest) so the pop candidate's address is available immediately.
-struct NodeRegs {
-    double2 n0, n1, n2;
-    int2 meta;
-};
-__device__ __forceinline__ NodeRegs load_node(const GNode *nodes, int idx) {
-    const double2 *q = reinterpret_cast<const double2 *>(nodes + idx);
-    NodeRegs n;
-    n.n0 = q[0]; n.n1 = q[1]; n.n2 = q[2];
-    n.meta = *reinterpret_cast<const int2 *>(&q[3]);
-    return n;
-}
-
 template <bool ANY>
-__device__ __forceinline__ int traverse_pf(const DScene &sc, Ray &r, int *stack, double &b1o, double &b2o,
-                                           unsigned &nvis, unsigned &ntri) {
-    int result = ANY ? 0 : -1;
-    if (sc.n_nodes == 0) return result;
-    const double invx = 1.0 / r.d.x, invy = 1.0 / r.d.y, invz = 1.0 / r.d.z;
-    const bool negx = r.d.x < 0.0, negy = r.d.y < 0.0, negz = r.d.z < 0.0;
-    int todo_idx = 0, top = 0, node_idx = 0;
-    NodeRegs cur = load_node(sc.nodes, 0);
-    for (;;) {
-        const int nprim = cur.meta.y & 0xFFFF;
-        const int axis = cur.meta.y >> 16;
-        const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-        const int near_idx = neg ? cur.meta.x : node_idx + 1;
-        const int far_idx = neg ? node_idx + 1 : cur.meta.x;
-        // speculative successors (indices were validated on the host at upload)
-        const NodeRegs A = load_node(sc.nodes, nprim == 0 ? near_idx : 0);
-        const NodeRegs B = load_node(sc.nodes, todo_idx > 0 ? top : 0);
-        nvis++;
-        const double2 n0 = cur.n0, n1 = cur.n1, n2 = cur.n2;
-        double tmin = ((negx ? n1.y : n0.x) - r.o.x) * invx;
-        double tmax = ((negx ? n0.x : n1.y) - r.o.x) * invx;
-        double tmin_y = ((negy ? n2.x : n0.y) - r.o.y) * invy;
-        double tmax_y = ((negy ? n0.y : n2.x) - r.o.y) * invy;
-        bool hitbox = !(tmin > tmax_y || tmin_y > tmax);
-        if (tmin_y > tmin) tmin = tmin_y;
-        if (tmax_y < tmax) tmax = tmax_y;
-        double tmin_z = ((negz ? n2.y : n1.x) - r.o.z) * invz;
-        double tmax_z = ((negz ? n1.x : n2.y) - r.o.z) * invz;
-        hitbox = hitbox && !(tmin > tmax_z || tmin_z > tmax);
-        if (tmin_z > tmin) tmin = tmin_z;
-        if (tmax_z < tmax) tmax = tmax_z;
-        hitbox = hitbox && (tmin < r.maxt) && (tmax > r.mint);
-        if (hitbox && nprim == 0) {
-            if (todo_idx > 0) stack[(todo_idx - 1) * PT_BLOCK] = top;
-            top = far_idx;
-            todo_idx++;
-            node_idx = near_idx;
-            cur = A;
-        } else {
-            if (hitbox) {
-                for (int i = 0; i < nprim; i++) {
-                    double t, b1, b2;
-                    ntri++;
-                    if (tri_test(sc.tris + cur.meta.x + i, r, t, b1, b2)) {
-                        if (ANY) return 1;
-                        result = cur.meta.x + i;
-                        b1o = b1; b2o = b2;
-                        r.maxt = t;
-                    }
-                }
-            }
-            if (todo_idx == 0) break;
-            node_idx = top;
-            cur = B;
-            todo_idx--;
-            if (todo_idx > 0) top = stack[(todo_idx - 1) * PT_BLOCK];
-        }
-    }
-    return result;
-}
-
-template <bool ANY, int VAR>
 __device__ __forceinline__ void trace_one(const DScene &sc, const double *__restrict__ rays, long stride, long i,
                                           int *stack, int *__restrict__ out_prim, double *__restrict__ out_t,
                                           double *__restrict__ out_b1, double *__restrict__ out_b2,
@@ -339,9 +134,7 @@ __device__ __forceinline__ void trace_one(const DScene &sc, const double *__rest
     r.mint = rays[6 * stride + i];
     r.maxt = rays[7 * stride + i];
     double b1 = 0., b2 = 0.;
-    int res = VAR == 2 ? traverse_pf<ANY>(sc, r, stack, b1, b2, nvis, ntri)
-            : VAR == 3 ? traverse<ANY, true>(sc, r, stack, b1, b2, nvis, ntri)
-                       : traverse<ANY, false>(sc, r, stack, b1, b2, nvis, ntri);
+    int res = traverse<ANY>(sc, r, stack, b1, b2, nvis, ntri);
     if (out_prim) out_prim[i] = res;
     if (!ANY) {
         if (out_t) out_t[i] = r.maxt;
@@ -355,166 +148,53 @@ __device__ __forceinline__ void trace_one(const DScene &sc, const double *__rest
     }
 }
 
-// ---- variant 1: "while-while" with dynamic ray fetch -------------------------------------
-// Same per-ray operation sequence as traverse<> (so results stay bit-identical), but the wave
-// is re-converged around the two expensive phases: all lanes first walk interior nodes until
-// each holds a leaf (or has finished), then the leaf triangles are tested with most lanes
-// active, instead of paying the divergent triangle code on almost every node step.  A lane
-// whose ray has finished pulls the next ray index from a global counter (one wave-aggregated
-// atomic), so a wave does not idle behind its longest ray.
+// Two input shapes:
+//  - dense (seg_counts == nullptr): rays [0, n_val), static grid-stride (pt_intersect);
+//  - segmented (the render queues, pt_kernels.h "segmented queues"): PT_SEG regions of `seg`
+//    entries, region r filled to seg_counts[r]; wave w serves region w % PT_SEG together with
+//    the other waves of the same residue.
+// Scheduling alternatives measured and rejected (while-while with per-lane refill, software
+// prefetch of the next node, scalar loads for wave-uniform nodes, dynamic and permuted chunk
+// assignment) are in the history of this file and in DESIGN.md "trace: what was tried".
 template <int STACK, bool ANY>
-__global__ __launch_bounds__(PT_BLOCK) void k_trace_ww(DScene sc, const double *__restrict__ rays, long stride,
-                                                       const int *__restrict__ n_ptr, int n_val,
-                                                       int *__restrict__ out_prim, double *__restrict__ out_t,
-                                                       double *__restrict__ out_b1, double *__restrict__ out_b2,
-                                                       ShadowResolve rs, unsigned long long *counters,
-                                                       int *__restrict__ next_ray) {
+__global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, const double *__restrict__ rays, long stride,
+                                                    const int *__restrict__ seg_counts, long seg, int n_val,
+                                                    int *__restrict__ out_prim, double *__restrict__ out_t,
+                                                    double *__restrict__ out_b1, double *__restrict__ out_b2,
+                                                    ShadowResolve rs, unsigned long long *counters) {
     __shared__ int s_stack[STACK * PT_BLOCK];
-    int *stack = s_stack + threadIdx.x;
-    const int n = n_ptr ? *n_ptr : n_val;
     unsigned nvis = 0, ntri = 0, nray = 0;
-    const bool empty_scene = sc.n_nodes == 0;
-
-    bool have = false, exhausted = false;
-    int ray_i = 0;
-    Ray r;
-    double invx = 0, invy = 0, invz = 0, b1 = 0., b2 = 0.;
-    bool negx = false, negy = false, negz = false;
-    int todo_idx = 0, node_idx = 0, result = 0, leaf_off = 0, leaf_cnt = 0;
-    r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 0); r.mint = 0; r.maxt = 0;
-
-    for (;;) {
-        // ---- (re)fetch: lanes without a ray take the next indices -----------------------------
-        const unsigned long long idle = __ballot(!have && !exhausted);
-        if (idle != 0ull) {
-            const bool want = !have && !exhausted;
-            const int leader = __ffsll((long long)idle) - 1;
-            int base = 0;
-            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(next_ray, __popcll(idle));
-            base = __shfl(base, leader);
-            if (want) {
-                ray_i = base + (int)lane_prefix(idle);
-                if (ray_i < n) {
-                    r.o = mk3(rays[ray_i], rays[stride + ray_i], rays[2 * stride + ray_i]);
-                    r.d = mk3(rays[3 * stride + ray_i], rays[4 * stride + ray_i], rays[5 * stride + ray_i]);
-                    r.mint = rays[6 * stride + ray_i];
-                    r.maxt = rays[7 * stride + ray_i];
-                    invx = 1.0 / r.d.x; invy = 1.0 / r.d.y; invz = 1.0 / r.d.z;
-                    negx = r.d.x < 0.0; negy = r.d.y < 0.0; negz = r.d.z < 0.0;
-                    todo_idx = 0; node_idx = 0; leaf_cnt = 0;
-                    result = ANY ? 0 : -1;
-                    b1 = 0.; b2 = 0.;
-                    have = true;
-                    nray++;
-                } else {
-                    exhausted = true;
-                }
+    if (seg_counts) {
+        const int lane = threadIdx.x & 63;
+        const int wave = (int)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6);
+        const int nsub = (int)((gridDim.x * (PT_BLOCK / 64)) / PT_SEG);
+        const int r = wave % PT_SEG, sub = wave / PT_SEG;
+        if (sub < nsub) {
+            const int n = seg_counts[r];
+            const long first = (long)r * seg;
+            for (int k = sub * 64 + lane; k < n; k += nsub * 64) {
+                trace_one<ANY>(sc, rays, stride, first + k, s_stack + threadIdx.x, out_prim, out_t, out_b1, out_b2, rs,
+                               nvis, ntri);
+                nray++;
             }
         }
-        if (__ballot(have) == 0ull) break;
-        bool done = !have || empty_scene;
-        // ---- phase 1: interior walk until this lane holds a leaf or is done -----------------
-        while (!done && leaf_cnt == 0) {
-            const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node_idx);
-            double2 n0 = q[0], n1 = q[1], n2 = q[2];
-            int2 meta = *reinterpret_cast<const int2 *>(&q[3]);
-            nvis++;
-            double tmin = ((negx ? n1.y : n0.x) - r.o.x) * invx;
-            double tmax = ((negx ? n0.x : n1.y) - r.o.x) * invx;
-            double tmin_y = ((negy ? n2.x : n0.y) - r.o.y) * invy;
-            double tmax_y = ((negy ? n0.y : n2.x) - r.o.y) * invy;
-            bool hitbox = !(tmin > tmax_y || tmin_y > tmax);
-            if (tmin_y > tmin) tmin = tmin_y;
-            if (tmax_y < tmax) tmax = tmax_y;
-            double tmin_z = ((negz ? n2.y : n1.x) - r.o.z) * invz;
-            double tmax_z = ((negz ? n1.x : n2.y) - r.o.z) * invz;
-            hitbox = hitbox && !(tmin > tmax_z || tmin_z > tmax);
-            if (tmin_z > tmin) tmin = tmin_z;
-            if (tmax_z < tmax) tmax = tmax_z;
-            hitbox = hitbox && (tmin < r.maxt) && (tmax > r.mint);
-            if (hitbox) {
-                const int nprim = meta.y & 0xFFFF;
-                if (nprim > 0) {
-                    leaf_off = meta.x; leaf_cnt = nprim;
-                } else {
-                    const int axis = meta.y >> 16;
-                    const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-                    stack[(todo_idx++) * PT_BLOCK] = neg ? node_idx + 1 : meta.x;
-                    node_idx = neg ? meta.x : node_idx + 1;
-                }
-            } else {
-                if (todo_idx == 0) done = true;
-                else node_idx = stack[(--todo_idx) * PT_BLOCK];
-            }
-        }
-        // ---- phase 2: the leaf ---------------------------------------------------------------
-        if (leaf_cnt > 0) {
-            for (int k = 0; k < leaf_cnt; k++) {
-                double t, tb1, tb2;
-                ntri++;
-                if (tri_test(sc.tris + leaf_off + k, r, t, tb1, tb2)) {
-                    if (ANY) { result = 1; done = true; break; }
-                    result = leaf_off + k;
-                    b1 = tb1; b2 = tb2;
-                    r.maxt = t;
-                }
-            }
-            leaf_cnt = 0;
-            if (!done) {
-                if (todo_idx == 0) done = true;
-                else node_idx = stack[(--todo_idx) * PT_BLOCK];
-            }
-        }
-        // ---- retire -------------------------------------------------------------------------
-        if (have && done) {
-            if (out_prim) out_prim[ray_i] = result;
-            if (!ANY) {
-                if (out_t) out_t[ray_i] = r.maxt;
-                if (out_b1) out_b1[ray_i] = b1;
-                if (out_b2) out_b2[ray_i] = b2;
-            } else if (rs.L && result == 0) {
-                const int slot = rs.slot[ray_i];
-                unsafeAtomicAdd(rs.L + slot, rs.c[ray_i]);
-                unsafeAtomicAdd(rs.L + rs.lstride + slot, rs.c[rs.cstride + ray_i]);
-                unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + ray_i]);
-            }
-            have = false;
+    } else {
+        for (long i = (long)blockIdx.x * PT_BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * PT_BLOCK) {
+            trace_one<ANY>(sc, rays, stride, i, s_stack + threadIdx.x, out_prim, out_t, out_b1, out_b2, rs, nvis, ntri);
+            nray++;
         }
     }
     if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
 }
 
 template <bool ANY>
-static hipError_t launch_trace_t(int variant, int *next_ray, int chunk, int stack, int grid, hipStream_t stream, const DScene &sc,
-                                 const double *rays, long stride, const int *n_ptr, int n_val, int *out_prim,
-                                 double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
+static hipError_t launch_trace_t(int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                                 long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
+                                 double *out_b1, double *out_b2, const ShadowResolve &rs,
                                  unsigned long long *counters) {
-#define PT_LAUNCH(S)                                                                                          \
-    do {                                                                                                      \
-        if (variant == 1)                                                                                     \
-            hipLaunchKernelGGL((k_trace_ww<S, ANY>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays, stride, \
-                               n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, next_ray);        \
-        else if (variant == 2)                                                                                \
-            hipLaunchKernelGGL((k_trace<S, ANY, 2>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays,         \
-                               stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, next_ray, \
-                               chunk);                                                                        \
-        else if (variant == 4)                                                                                \
-            hipLaunchKernelGGL((k_trace<S, ANY, 4>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays,         \
-                               stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, next_ray, \
-                               chunk);                                                                        \
-        else if (variant == 5)                                                                                \
-            hipLaunchKernelGGL((k_trace<S, ANY, 5>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays,         \
-                               stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, next_ray, \
-                               7919);                                                                         \
-        else if (variant == 3)                                                                                \
-            hipLaunchKernelGGL((k_trace<S, ANY, 3>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays,         \
-                               stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, next_ray, \
-                               chunk);                                                                        \
-        else                                                                                                  \
-            hipLaunchKernelGGL((k_trace<S, ANY, 0>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays,         \
-                               stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, next_ray, \
-                               chunk);                                                                        \
-    } while (0)
+#define PT_LAUNCH(S)                                                                                       \
+    hipLaunchKernelGGL((k_trace<S, ANY>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rays, stride, seg_counts, \
+                       seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters)
     if (stack <= 16) PT_LAUNCH(16);
     else if (stack <= 24) PT_LAUNCH(24);
     else if (stack <= 32) PT_LAUNCH(32);
@@ -527,21 +207,9 @@ static hipError_t launch_trace_t(int variant, int *next_ray, int chunk, int stac
 // Resident workgroups per CU of the trace kernel that pt_launch_trace would pick (advisory
 // occupancy API; used only to size the grid to one full residency round, never for correctness).
 template <bool ANY>
-static int trace_occupancy_t(int variant, int stack) {
+static int trace_occupancy_t(int stack) {
     int nb = 0;
-#define PT_OCC(S)                                                                                              \
-    do {                                                                                                       \
-        if (variant == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_ww<S, ANY>, PT_BLOCK, 0); \
-        else if (variant == 2)                                                                                 \
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<S, ANY, 2>, PT_BLOCK, 0);          \
-        else if (variant == 3)                                                                                 \
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<S, ANY, 3>, PT_BLOCK, 0);          \
-        else if (variant == 4)                                                                                 \
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<S, ANY, 4>, PT_BLOCK, 0);          \
-        else if (variant == 5)                                                                                 \
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<S, ANY, 5>, PT_BLOCK, 0);          \
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<S, ANY, 0>, PT_BLOCK, 0);         \
-    } while (0)
+#define PT_OCC(S) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<S, ANY>, PT_BLOCK, 0)
     if (stack <= 16) PT_OCC(16);
     else if (stack <= 24) PT_OCC(24);
     else if (stack <= 32) PT_OCC(32);
@@ -550,26 +218,16 @@ static int trace_occupancy_t(int variant, int stack) {
 #undef PT_OCC
     return nb > 0 ? nb : 4;
 }
-int pt_trace_occupancy(int variant, bool any, int stack) {
-    return any ? trace_occupancy_t<true>(variant, stack) : trace_occupancy_t<false>(variant, stack);
+int pt_trace_occupancy(bool any, int stack) {
+    return any ? trace_occupancy_t<true>(stack) : trace_occupancy_t<false>(stack);
 }
 
-hipError_t pt_launch_trace(int variant, int *next_ray, bool any, int stack, int grid, hipStream_t stream,
-                           const DScene &sc, const double *rays, long stride, const int *n_ptr, int n_val,
-                           int *out_prim, double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
-                           unsigned long long *counters, long n_bound) {
-    int chunk = 64;
-    if (variant == 1 || variant == 4) {   // the dynamic ray counters start at 0 for every launch
-        hipError_t e = hipMemsetAsync(next_ray, 0, 8 * sizeof(int), stream);
-        if (e != hipSuccess) return e;
-        // chunk = 64*R consecutive rays per fetch: ~32 fetches per wave, at most 8 x 64 rays at a time
-        const long waves = (long)grid * (PT_BLOCK / 64);
-        long R = n_bound / (64 * waves * 32);
-        R = R < 1 ? 1 : (R > 8 ? 8 : R);
-        chunk = (int)(64 * R);
-    }
-    if (any) return launch_trace_t<true>(variant, next_ray, chunk, stack, grid, stream, sc, rays, stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
-    return launch_trace_t<false>(variant, next_ray, chunk, stack, grid, stream, sc, rays, stride, n_ptr, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                           long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
+                           double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
+    if (seg_counts) grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
+    if (any) return launch_trace_t<true>(stack, grid, stream, sc, rays, stride, seg_counts, seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    return launch_trace_t<false>(stack, grid, stream, sc, rays, stride, seg_counts, seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
 }
 
 // =========================================================================================
@@ -660,6 +318,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
                                                      Queue q, PathState st, unsigned long long *counters) {
     const RenderConst &rc = *rcp;
     const int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < PT_SEG) {
+        // fill level of every region, known in closed form
+        const int r = threadIdx.x, nfull = nb >> 6, rem = nb & 63;
+        q.count[r] = 64 * (nfull / PT_SEG + (r < nfull % PT_SEG ? 1 : 0)) + (r == nfull % PT_SEG ? rem : 0);
+    }
     if (i >= nb) return;
     int px, py, si;
     uint32_t sid;
@@ -690,11 +353,15 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
     }
     o = xf4_point(rc.cam.c2w, o);
     d = xf_vec(rc.cam.c2w, d);
+    // sample i of the batch goes to region (i/64) % PT_SEG of the segmented queue, behind the
+    // earlier 64-sample chunks of the same residue
     const long S = q.stride;
-    q.rays[i] = o.x; q.rays[S + i] = o.y; q.rays[2 * S + i] = o.z;
-    q.rays[3 * S + i] = d.x; q.rays[4 * S + i] = d.y; q.rays[5 * S + i] = d.z;
-    q.rays[6 * S + i] = 0.; q.rays[7 * S + i] = __builtin_inf();
-    q.slot[i] = i;
+    const int ch = i >> 6;
+    const long e = (long)(ch % PT_SEG) * q.seg + (long)(ch / PT_SEG) * 64 + (i & 63);
+    q.rays[e] = o.x; q.rays[S + e] = o.y; q.rays[2 * S + e] = o.z;
+    q.rays[3 * S + e] = d.x; q.rays[4 * S + e] = d.y; q.rays[5 * S + e] = d.z;
+    q.rays[6 * S + e] = 0.; q.rays[7 * S + e] = __builtin_inf();
+    q.slot[e] = i;
     const long P = st.stride;
     st.T[i] = 1.; st.T[P + i] = 1.; st.T[2 * P + i] = 1.;
     st.L[i] = 0.; st.L[P + i] = 0.; st.L[2 * P + i] = 0.;
@@ -736,9 +403,11 @@ __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, con
     return true;
 }
 
-__device__ __forceinline__ void push_shadow(const ShadowQueue &sh, bool pred, const Ray &r, d3 c, int slot) {
-    int pos = wave_append(pred, sh.count);
+__device__ __forceinline__ void push_shadow(const ShadowQueue &sh, int region, bool pred, const Ray &r, d3 c,
+                                            int slot) {
+    long pos = wave_append(pred, sh.count + region);
     if (pos >= 0) {
+        pos += (long)region * sh.seg;
         const long S = sh.stride;
         sh.rays[pos] = r.o.x; sh.rays[S + pos] = r.o.y; sh.rays[2 * S + pos] = r.o.z;
         sh.rays[3 * S + pos] = r.d.x; sh.rays[4 * S + pos] = r.d.y; sh.rays[5 * S + pos] = r.d.z;
@@ -761,10 +430,18 @@ template <int KIND>
 __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
                                                     int level, Queue qin, Queue qout, ShadowQueue sh, PathState st) {
     const RenderConst &rc = *rcp;
-    const int n = *qin.count;
+    // wave w serves region w % PT_SEG of the input queue and appends to the SAME region of both
+    // output queues (pt_kernels.h "segmented queues")
+    const int wave = (int)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6);
+    const int nsub = (int)((gridDim.x * (PT_BLOCK / 64)) / PT_SEG);
+    const int region = wave % PT_SEG, sub = wave / PT_SEG;
+    if (sub >= nsub) return;
+    const int n = qin.count[region];
     const int nloop = (n + 63) & ~63;   // whole waves stay convergent for the ballots
-    for (int i = blockIdx.x * PT_BLOCK + threadIdx.x; i < nloop; i += gridDim.x * PT_BLOCK) {
-        const bool live = i < n;
+    const long first = (long)region * qin.seg;
+    for (int k = sub * 64 + (int)(threadIdx.x & 63); k < nloop; k += nsub * 64) {
+        const bool live = k < n;
+        const long i = first + k;
         int slot = 0, prim = -1;
         if (live) { slot = qin.slot[i]; prim = qin.prim[i]; }
         const long P = st.stride, S = qin.stride;
@@ -810,7 +487,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                         need = estimate_direct(sc, sc.lights[li], vx, wo, u0, u1, sr, c);
                         c = T * (c / (double)ns);
                     }
-                    push_shadow(sh, need, sr, c, slot);
+                    push_shadow(sh, region, need, sr, c, slot);
                 }
             }
             if (hit && (level + 1 < rc.ig.max_depth)) {
@@ -850,7 +527,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                 need = estimate_direct(sc, sc.lights[ln], vx, wo, u0, u1, sr, c);
                 c = T * (c * (double)sc.n_lights);
             }
-            push_shadow(sh, need, sr, c, slot);
+            push_shadow(sh, region, need, sr, c, slot);
             if (hit) {
                 double u0, u1, uc;
                 if (level < 3) {
@@ -880,8 +557,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                 }
             }
         }
-        int pos = wave_append(cont, qout.count);
+        long pos = wave_append(cont, qout.count + region);
         if (pos >= 0) {
+            pos += (long)region * qout.seg;
             const long SO = qout.stride;
             qout.rays[pos] = nray.o.x; qout.rays[SO + pos] = nray.o.y; qout.rays[2 * SO + pos] = nray.o.z;
             qout.rays[3 * SO + pos] = nray.d.x; qout.rays[4 * SO + pos] = nray.d.y; qout.rays[5 * SO + pos] = nray.d.z;
@@ -901,6 +579,7 @@ hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc,
 hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,
                            int level, const Queue &qin, const Queue &qout, const ShadowQueue &sh,
                            const PathState &st) {
+    grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
     if (kind == PT_INTEG_DIRECT)
         hipLaunchKernelGGL((k_shade<PT_INTEG_DIRECT>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, qout, sh, st);
     else
@@ -1062,11 +741,5 @@ __global__ __launch_bounds__(PT_BLOCK) void k_film_resolve(const double *__restr
 hipError_t pt_launch_film_resolve(hipStream_t stream, const double *acc, long npix, double *rgb) {
     const int grid = (int)((npix + PT_BLOCK - 1) / PT_BLOCK);
     if (grid > 0) hipLaunchKernelGGL(k_film_resolve, dim3(grid), dim3(PT_BLOCK), 0, stream, acc, npix, rgb);
-    return hipGetLastError();
-}
-
-__global__ void k_set_int(int *p, int v) { *p = v; }
-hipError_t pt_launch_set_int(hipStream_t stream, int *p, int v) {
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, stream, p, v);
     return hipGetLastError();
 }
