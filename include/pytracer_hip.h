@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 typedef enum {
     PT_OK = 0,
@@ -201,6 +201,28 @@ int pt_set_profiling(pt_ctx *ctx, int enable);
  * [y][x][3]. */
 int pt_film_resolve(pt_ctx *ctx, const double *film_accum, int32_t x_cnt, int32_t y_cnt,
                     double *rgb, void *stream);
+
+/* replaces: BVH.__init__ → _recursive_build → _flatten_tree (aggregate/accelerator/bvh.py:
+ * 68-107,152-275,277-293, with _partition :110-120, _insertion_sort :123-130,
+ * _bucket_partition :133-150).  Host-side, needs no GPU and no context.  The tree, the bounds
+ * and the primitive order are those of the Python build (SAH with 12 buckets, traversal cost
+ * .125; n_prim <= 4 → insertion sort + median; the partition loops that never classify element
+ * k; the mid==start/end fix-ups), so primitive ids and traversal order match the reference.
+ *   prim_bounds  host f64 [n][6] = Primitive.world_bound() pMin[3], pMax[3] of every refined
+ *                primitive, in the order of BVH.primitives BEFORE the build (bvh.py:70-73,91)
+ *   method       PT_BVH_SAH ('sah') or PT_BVH_MIDDLE ('middle'), bvh.py:75-83
+ *   node_bounds  host f64 [2n-1][6], node_meta host i32 [2n-1][3] = (offset, n_prim, axis) as in
+ *                pt_scene_desc; prim_order host i32 [n]: ordered_prims[k] = primitives[prim_order[k]]
+ *   n_nodes      out: nodes written (0 for n == 0: the reference leaves BVH.nodes = None)
+ *   max_depth    out, may be NULL: depth of the tree (pt_scene_upload rejects > 64)
+ * Returns PT_ERR_ARG where the reference itself fails (its asserts at bvh.py:227,267-268; the
+ * TypeError of the unreachable-by-default leaf branch :261-265); pt_build_last_error() has the
+ * text (thread-local; valid until the next pt_bvh_build on the same thread). */
+typedef enum { PT_BVH_SAH = 0, PT_BVH_MIDDLE = 1 } pt_bvh_method;
+int pt_bvh_build(const double *prim_bounds, int64_t n, int32_t max_prim_per_node, int32_t method,
+                 double *node_bounds, int32_t *node_meta, int32_t *prim_order, int64_t *n_nodes,
+                 int32_t *max_depth);
+const char *pt_build_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """ctypes mirror of include/pytracer_hip.h (struct layouts and enums only)."""
 import ctypes as C
 
-PT_ABI_VERSION = 2
+PT_ABI_VERSION = 3
 PT_MAX_LOBES = 5
 
 PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
@@ -9,6 +9,7 @@ PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 
 PT_LOBE_LAMBERT, PT_LOBE_OREN_NAYAR, PT_LOBE_MICROFACET_BLINN, PT_LOBE_SPEC_REFLECT, PT_LOBE_SPEC_TRANSMIT = range(5)
 PT_LIGHT_DIFFUSE_SPHERE, PT_LIGHT_SPOT, PT_LIGHT_POINT = range(3)
 PT_INTEG_DIRECT, PT_INTEG_PATH = 0, 1
+PT_BVH_SAH, PT_BVH_MIDDLE = 0, 1
 
 
 class pt_lobe(C.Structure):

@@ -282,12 +282,15 @@ def flatten_scene(scene):
     agg = scene.aggregate
     nodes = agg.nodes or []
     prims = agg.primitives
-    nb = np.empty((len(nodes), 6), np.float64)
-    nm = np.empty((len(nodes), 3), np.int32)
-    for i, nd in enumerate(nodes):
-        nb[i, 0:3] = nd.bounds.pMin
-        nb[i, 3:6] = nd.bounds.pMax
-        nm[i] = (nd.offset, nd.n_prim, nd.axis)
+    if getattr(agg, 'flat_nodes', None) is not None:       # pytracer_amd.accel.BVH keeps the arrays
+        nb, nm = agg.flat_nodes
+    else:
+        nb = np.empty((len(nodes), 6), np.float64)
+        nm = np.empty((len(nodes), 3), np.int32)
+        for i, nd in enumerate(nodes):
+            nb[i, 0:3] = nd.bounds.pMin
+            nb[i, 3:6] = nd.bounds.pMax
+            nm[i] = (nd.offset, nd.n_prim, nd.axis)
     tv = np.empty((len(prims), 9), np.float64)
     tm = np.empty(len(prims), np.int32)
     tf = np.empty(len(prims), np.int32)

@@ -68,8 +68,24 @@ def main():
     dist = dl.norm(dim=0)
     sh[3:6] = dl / dist
     sh[7] = dist * (1 - 1e-5)
+    # the same secondary rays regrouped: does direction coherence inside a wave pay?
+    octant = ((sec[3] < 0).long() * 4 + (sec[4] < 0).long() * 2 + (sec[5] < 0).long())
+    M = sec.shape[1]
+    idx = torch.arange(M, device=dev)
+    sets = [('camera', cam), ('random-secondary', sec), ('to-light', sh)]
+    for win in (4096, 65536, M):
+        key = (idx // win) * 8 + octant
+        order = torch.argsort(key, stable=True)
+        sets.append(('sec octant/%d' % win, sec[:, order].contiguous()))
+    # finer direction bins (octant x 4 x 4 by the two minor components), windows of 65536
+    ax = sec[3:6].abs()
+    fine = octant * 16 + (ax[0] * 3.999).long().clamp(0, 3) * 4 + (ax[1] * 3.999).long().clamp(0, 3)
+    for win in (65536, M):
+        order = torch.argsort((idx // win) * 128 + fine, stable=True)
+        sets.append(('sec fine128/%d' % win, sec[:, order].contiguous()))
+    sets.append(('sec shuffled', sec[:, torch.randperm(M, device=dev, generator=g)].contiguous()))
     torch.cuda.synchronize()
-    for name, rays in (('camera', cam), ('random-secondary', sec), ('to-light', sh)):
+    for name, rays in sets:
         for any_hit in (False, True):
             best = None
             for _ in range(args.reps):
