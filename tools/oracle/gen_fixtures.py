@@ -115,6 +115,9 @@ def dump_scene(scene, camera=None):
                              Kr=np.array(mt.Kr(None)), Kt=np.array(mt.Kt(None)),
                              roughness=float(mt.roughness(None)), opacity=np.array(mt.opacity(None)),
                              eta=float(mt.eta(None))))
+        elif nm == 'PlasticMaterial':
+            mrec.append(dict(kind=2, Kd=np.array(mt.Kd(None)), Ks=np.array(mt.Ks(None)),
+                             roughness=float(mt.roughness(None))))
         else:
             raise NotImplementedError(nm)
     d['n_materials'] = np.int32(len(mrec))
@@ -211,7 +214,8 @@ def instrumented_render(model, x_res, y_res, xs, ys, integrator, seed, jitter=Tr
 
     o_int, o_intp = type(scene).intersect, type(scene).intersect_p
     o_ed = iutil.estimate_direct
-    o_sl = light_mod.DiffuseAreaLight.sample_l
+    sl_classes = (light_mod.DiffuseAreaLight, light_mod.SpotLight, light_mod.PointLight)
+    o_sls = [c.sample_l for c in sl_classes]
     o_sf = BSDF.sample_f
 
     def w_int(self, ray, isect):
@@ -243,12 +247,15 @@ def instrumented_render(model, x_res, y_res, xs, ys, integrator, seed, jitter=Tr
                         bsdf_smp.u_dir[0], bsdf_smp.u_dir[1], bsdf_smp.u_com) + tuple(Ld))
         return Ld
 
-    def w_sl(self, p, pEps, ls, time_):
-        r = o_sl(self, p, pEps, ls, time_)
-        Li, wi, pdf, vis = r
-        logs.sl.append(tuple(p) + (pEps, ls.u_pos[0], ls.u_pos[1], ls.u_com) + tuple(Li) + tuple(wi) + (pdf,) +
-                       tuple(vis.ray.o) + tuple(vis.ray.d) + (vis.ray.mint, vis.ray.maxt))
-        return r
+    def make_w_sl(o_sl):
+        def w_sl(self, p, pEps, ls, time_):
+            r = o_sl(self, p, pEps, ls, time_)
+            Li, wi, pdf, vis = r
+            logs.sl.append(tuple(p) + (pEps, ls.u_pos[0], ls.u_pos[1], ls.u_com) + tuple(Li) + tuple(wi) + (pdf,) +
+                           tuple(vis.ray.o) + tuple(vis.ray.d) + (vis.ray.mint, vis.ray.maxt) +
+                           (scene.lights.index(self),))
+            return r
+        return w_sl
 
     def w_sf(self, wo_w, smp, flags):
         r = o_sf(self, wo_w, smp, flags)
@@ -263,7 +270,8 @@ def instrumented_render(model, x_res, y_res, xs, ys, integrator, seed, jitter=Tr
     type(scene).intersect = w_int
     type(scene).intersect_p = w_intp
     iutil.estimate_direct = w_ed
-    light_mod.DiffuseAreaLight.sample_l = w_sl
+    for c, o in zip(sl_classes, o_sls):
+        c.sample_l = make_w_sl(o)
     BSDF.sample_f = w_sf
     try:
         if integrator is not None:
@@ -303,7 +311,8 @@ def instrumented_render(model, x_res, y_res, xs, ys, integrator, seed, jitter=Tr
         type(scene).intersect = o_int
         type(scene).intersect_p = o_intp
         iutil.estimate_direct = o_ed
-        light_mod.DiffuseAreaLight.sample_l = o_sl
+        for c, o in zip(sl_classes, o_sls):
+            c.sample_l = o
         BSDF.sample_f = o_sf
     film = camera.film
     W, H = film.xPixel_cnt, film.yPixel_cnt
@@ -322,7 +331,8 @@ def instrumented_render(model, x_res, y_res, xs, ys, integrator, seed, jitter=Tr
                log_rres=np.array(logs.rres, np.float64).reshape(-1, 3),
                log_hitgeo=np.array(logs.hitgeo, np.float64).reshape(-1, 15),
                log_ed=np.array(logs.ed, np.float64).reshape(-1, 21),
-               log_sl=np.array(logs.sl, np.float64).reshape(-1, 22),
+               log_sl=np.array(logs.sl, np.float64).reshape(-1, 23)[:, :22],
+               log_sl_light=np.array(logs.sl, np.float64).reshape(-1, 23)[:, 22].astype(np.int32),
                log_sf=np.array(logs.sf, np.float64).reshape(-1, 15))
     out.update(dump_camera(camera))
     return out
@@ -425,7 +435,80 @@ def gen_bvh():
         print('bvh %s: %.1fs nodes %d hits %d' % (name, time.time() - t, len(bvh.nodes), int(res[:, 0].sum())))
 
 
-ALL = dict(scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
+class C4Mini(object):
+    """C4 in miniature: a triangle soup with alternating Matte / Plastic materials in
+    front of a matte wall, lit by a SpotLight, a PointLight and a sphere DiffuseAreaLight; camera at
+    (0,0,-30) looking +z, fov 60."""
+
+    def __init__(self):
+        from pytracer.shape import Sphere, create_triangle_mesh
+        from pytracer.transform import Transform
+        from pytracer.material import MatteMaterial, PlasticMaterial
+        from pytracer.texture import ConstantTexture
+        from pytracer.light import SpotLight, PointLight, DiffuseAreaLight
+        from pytracer.scene import Scene
+        rng = np.random.default_rng(4242)
+        n = 180
+        c = np.concatenate([rng.uniform(-9, 9, (n, 2)), rng.uniform(-5, 5, (n, 1))], axis=1)
+        e1 = rng.normal(0, 1.6, (n, 3))
+        e2 = rng.normal(0, 1.6, (n, 3))
+        tri = np.stack([c, c + e1, c + e2], 1)
+        ident = Transform.translate(geo.Vector(0., 0., 0.))
+        self.in_tris = []
+        prims = []
+        mats = [MatteMaterial(ConstantTexture(Spectrum([.6, .3, .2])), ConstantTexture(0.)),
+                PlasticMaterial(ConstantTexture(Spectrum([.2, .4, .6])), ConstantTexture(Spectrum([.3, .3, .3])),
+                                ConstantTexture(0.05)),
+                MatteMaterial(ConstantTexture(Spectrum([.5, .5, .5])), ConstantTexture(20.))]    # Oren-Nayar wall
+        for k in range(2):
+            P = tri[k::2].reshape(-1, 3)
+            mesh = create_triangle_mesh(ident, ident.inverse(), False,
+                                        {'indices': list(range(len(P))), 'P': list(P.ravel())})
+            prims.append(GeometricPrimitive(mesh, mats[k]))
+            self.in_tris.append(P.reshape(-1, 9))
+        wall = {'indices': [0, 1, 2, 2, 0, 3], 'P': [-30, -30, 9, 30, -30, 9, 30, 30, 9, -30, 30, 9]}
+        prims.append(GeometricPrimitive(create_triangle_mesh(ident, ident.inverse(), False, wall), mats[2]))
+        w = np.array(wall['P'], float).reshape(-1, 3)
+        self.in_tris.append(w[np.array(wall['indices'])].reshape(-1, 9))
+        # +z of the light frame towards the origin (Transform.look_at mixes up rows and columns, so compose)
+        spot_l2w = Transform.translate(geo.Vector(0., 15., -25.)) * Transform.rotate_x(np.rad2deg(np.arctan2(15., 25.)))
+        st = Transform.translate(geo.Vector(-10., 10., -20.))
+        sph = Sphere(st, st.inverse(), False, 3, -3, 3, 360.)
+        lights = [SpotLight(spot_l2w, Spectrum(200.), 30., 25.),
+                  PointLight(Transform.translate(geo.Vector(8., -6., -12.)), Spectrum(150.)),
+                  DiffuseAreaLight(st, Spectrum(10.), 2, sph)]
+        self.scene = Scene(BVH(prims), lights, None)
+
+    @staticmethod
+    def configure_camera(x_res=50, y_res=50, file_name='tmp.png'):
+        from pytracer.transform import Transform, AnimatedTransform
+        from pytracer.filter import LanczosSincFilter
+        from pytracer.film import ImageFilm
+        from pytracer.camera import PerspectiveCamera
+        fil = LanczosSincFilter(4., 4., 3.)
+        film = ImageFilm(x_res, y_res, fil, [0., 1., 0., 1.], file_name)
+        c_trans = Transform.translate(geo.Vector(0., 0., -30.))
+        return PerspectiveCamera(AnimatedTransform(c_trans, 0., c_trans, 0.), [0., 1., 0., 1.], 0., 0., 0., 1e100, 60.,
+                                 film)
+
+
+def gen_c4mini():
+    model = C4Mini()
+    cam = model.configure_camera(x_res=24, y_res=24, file_name='/tmp/_fixture.png')
+    sc = dump_scene(model.scene, cam)
+    for k, t in enumerate(model.in_tris):
+        sc['in_tris%d' % k] = t
+    for name, integ, xs in (('direct', DirectLightingIntegrator(), 1), ('path', PathIntegrator(max_depth=5), 2)):
+        t = time.time()
+        d = instrumented_render(model, 24, 24, xs, xs, integ, seed=7)
+        d.update(sc)
+        np.savez_compressed(os.path.join(OUT, 'c4mini_%s_24x24x%d.npz' % (name, xs * xs)), **d)
+        print('c4mini %s: %.1fs, rays logged %d, sumL %.6f, zero-L %d of %d, spot/point/sphere sample_l %s' % (
+            name, time.time() - t, len(d['log_rays']), d['L'].sum(), int((d['L'].sum(1) == 0).sum()), len(d['L']),
+            np.bincount(d['log_sl_light'], minlength=3)))
+
+
+ALL = dict(c4mini=gen_c4mini, scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)
