@@ -17,7 +17,8 @@ struct pt_ctx {
     // scene (device)
     bool have_scene;
     DScene sc;
-    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights;
+    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top;
+    int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
     int stack_need;          // deepest leaf = max simultaneous todo entries (bvh.py:332 allows 64)
     bool has_spec_reflect;   // any material with a SpecularReflection lobe (Direct recursion)
     int light_ns[16];
@@ -29,6 +30,8 @@ struct pt_ctx {
     Queue q[2];
     ShadowQueue sh;
     PathState st;
+    int use_top;             // PT_TRACE_TOP=1: stage the top of the tree in LDS (k_trace_top); measured 5 % slower
+                             // than the plain kernel on the head mesh, so off by default
     int *d_counts;           // [3][PT_SEG]: region fill counters of q0, q1 and the shadow queue
     int trace_occ[2];        // resident blocks/CU of the closest / any trace kernels (0 = not queried)
     RenderConst *d_rc;
@@ -94,6 +97,8 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATE_CHK(hipMalloc((void **)&c->d_counts, 3 * PT_SEG * sizeof(int)));
+    c->use_top = 0;
+    if (const char *e = getenv("PT_TRACE_TOP")) c->use_top = atoi(e);
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
     CREATE_CHK(hipMalloc((void **)&c->d_counters, PT_CNT_SHARDS * CNT_COUNT * sizeof(unsigned long long)));
     c->ev = new std::vector<hipEvent_t>();
@@ -149,7 +154,7 @@ static void collect_timing(pt_ctx *c, pt_stats *stats) {
 }
 
 static void free_scene(pt_ctx *c) {
-    void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights};
+    void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -273,6 +278,48 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
         g._pad = 0;
     }
     HIPCHK(c, upload(&c->d_nodes, nodes.data(), nodes.size()));
+    // top of the tree for k_trace_top: the first K nodes in breadth-first order, K from the LDS left
+    // beside 1024 per-lane stacks (160 KB per CU on gfx950)
+    int n_top = 0;
+    c->top_stack = 0;
+    {
+        const int levels = (std::max(depth, 1) + 3) & ~3;
+        long k = ((long)160 * 1024 - 1024 - (long)levels * 4096) / (long)sizeof(TopNode);
+        if (const char *e = getenv("PT_TOP_NODES")) k = std::min(k, atol(e));
+        k = std::min<long>(k, d->n_nodes);
+        if (k >= 64) {
+            std::vector<int> order, slot((size_t)d->n_nodes, -1);
+            order.reserve((size_t)k);
+            order.push_back(0);
+            for (size_t h = 0; h < order.size() && (long)order.size() < k; h++) {
+                const int i = order[h];
+                const int32_t *m = d->node_meta + 3 * (size_t)i;
+                if (m[1] == 0) {
+                    order.push_back(i + 1);
+                    if ((long)order.size() < k) order.push_back(m[0]);
+                }
+            }
+            for (size_t h = 0; h < order.size(); h++) slot[(size_t)order[h]] = (int)h;
+            std::vector<TopNode> top(order.size());
+            for (size_t h = 0; h < order.size(); h++) {
+                const int i = order[h];
+                const GNode &g = nodes[(size_t)i];
+                TopNode &t = top[h];
+                memcpy(t.bmin, g.bmin, sizeof(t.bmin));
+                memcpy(t.bmax, g.bmax, sizeof(t.bmax));
+                t.offset = g.offset;
+                t.nprim_axis = g.nprim_axis;
+                t.ref0 = t.ref1 = 0;
+                if ((g.nprim_axis & 0xFFFF) == 0) {
+                    t.ref0 = slot[(size_t)i + 1] >= 0 ? ~slot[(size_t)i + 1] : i + 1;
+                    t.ref1 = slot[(size_t)g.offset] >= 0 ? ~slot[(size_t)g.offset] : g.offset;
+                }
+            }
+            HIPCHK(c, upload(&c->d_top, top.data(), top.size()));
+            n_top = (int)top.size();
+            c->top_stack = levels;
+        }
+    }
     HIPCHK(c, upload(&c->d_tris, tris.data(), tris.size()));
     HIPCHK(c, upload(&c->d_verts, d->tri_verts, 9 * (size_t)d->n_tris));
     HIPCHK(c, upload(&c->d_mat, d->tri_mat, (size_t)d->n_tris));
@@ -281,6 +328,8 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     HIPCHK(c, upload(&c->d_lights, d->lights, (size_t)d->n_lights));
     DScene &s = c->sc;
     s.nodes = (const GNode *)c->d_nodes;
+    s.top = n_top ? (const TopNode *)c->d_top : nullptr;
+    s.n_top = n_top; s._pad0 = 0;
     s.tris = (const GTri *)c->d_tris;
     s.tri_verts = (const double *)c->d_verts;
     s.tri_mat = (const int32_t *)c->d_mat;
@@ -308,6 +357,20 @@ static int trace_grid(pt_ctx *c, long n, bool any) {
     if (const char *e = getenv("PT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1l, atol(e));
     long cap = (long)c->n_cu * per_cu;
     return (int)std::max<long>(1, std::min(blocks, cap));
+}
+
+// every trace launch goes through here: top-of-tree kernel when the tree qualified at upload
+static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t stream, const double *rays, long stride,
+                               const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t, double *out_b1,
+                               double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
+    if (c->top_stack > 0 && c->use_top) {
+        const long blocks = (n_bound + 1023) / 1024;
+        const int grid = (int)std::max<long>(1, std::min<long>(blocks, c->n_cu));
+        return pt_launch_trace_top(any, c->top_stack, grid, stream, c->sc, rays, stride, seg_counts, seg, n_val, out_prim,
+                                   out_t, out_b1, out_b2, rs, counters);
+    }
+    return pt_launch_trace(any, c->stack_need, trace_grid(c, n_bound, any), stream, c->sc, rays, stride, seg_counts, seg,
+                           n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
 }
 
 static int read_counters(pt_ctx *c, hipStream_t stream, pt_stats *stats) {
@@ -351,8 +414,8 @@ extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hi
     c->ev_used = 0;
     {
         StageTimer tm(c, stream, any_hit ? STAGE_TRACE_ANY : STAGE_TRACE_CLOSEST);
-        HIPCHK(c, pt_launch_trace(any_hit != 0, c->stack_need, trace_grid(c, n, any_hit != 0), stream, c->sc, rays,
-                                  (long)n, nullptr, 0, (int)n, prim, t, b1, b2, rs, cnt));
+        HIPCHK(c, launch_trace(c, any_hit != 0, (long)n, stream, rays, (long)n, nullptr, 0, (int)n, prim, t, b1, b2, rs,
+                               cnt));
     }
     if (stats) return read_counters(c, stream, stats);
     return PT_OK;
@@ -493,7 +556,6 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     for (long base = 0; base < total; base += batch) {
         const int nb = (int)std::min(batch, total - base);
         const int g = (nb + PT_BLOCK - 1) / PT_BLOCK;
-        const int gt = trace_grid(c, nb, false), gta = trace_grid(c, nb, true);
         const int gs = (int)std::max<long>(1, std::min<long>((nb + PT_BLOCK - 1) / PT_BLOCK, (long)c->n_cu * 4));
         {
             StageTimer tm(c, stream, STAGE_RAYGEN);
@@ -501,14 +563,13 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         }
         if (ig->pretest) {   // renderer.py:168: same hit flag as the closest-hit pass below
             StageTimer tm(c, stream, STAGE_TRACE_ANY);
-            HIPCHK(c, pt_launch_trace(true, c->stack_need, gta, stream, c->sc, c->q[0].rays, c->q[0].stride,
-                                      c->q[0].count, c->q[0].seg, 0, nullptr, nullptr, nullptr, nullptr, no_rs, cnt));
+            HIPCHK(c, launch_trace(c, true, nb, stream, c->q[0].rays, c->q[0].stride, c->q[0].count, c->q[0].seg, 0,
+                                   nullptr, nullptr, nullptr, nullptr, no_rs, cnt));
         }
         {
             StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-            HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, c->q[0].rays, c->q[0].stride,
-                                      c->q[0].count, c->q[0].seg, 0, c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2,
-                                      no_rs, cnt));
+            HIPCHK(c, launch_trace(c, false, nb, stream, c->q[0].rays, c->q[0].stride, c->q[0].count, c->q[0].seg, 0,
+                                   c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
         }
         int cur = 0;
         for (int level = 0; level < levels; level++) {
@@ -522,9 +583,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             ShadowResolve rs = {c->sh.c, c->sh.stride, c->sh.slot, c->st.L, c->st.stride};
             {
                 StageTimer tm(c, stream, STAGE_TRACE_ANY);
-                HIPCHK(c, pt_launch_trace(true, c->stack_need, trace_grid(c, (long)nb * spv, true), stream, c->sc,
-                                          c->sh.rays, c->sh.stride, c->sh.count, c->sh.seg, 0, nullptr, nullptr,
-                                          nullptr, nullptr, rs, cnt));
+                HIPCHK(c, launch_trace(c, true, (long)nb * spv, stream, c->sh.rays, c->sh.stride, c->sh.count, c->sh.seg,
+                                       0, nullptr, nullptr, nullptr, nullptr, rs, cnt));
             }
             if (getenv("PT_DEBUG_LEVELS") && base == 0) {   // debugging aid: queue sizes per level (syncs)
                 int h[3 * PT_SEG];
@@ -537,8 +597,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             }
             if (level + 1 < levels) {
                 StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-                HIPCHK(c, pt_launch_trace(false, c->stack_need, gt, stream, c->sc, qout.rays, qout.stride, qout.count,
-                                          qout.seg, 0, qout.prim, qout.t, qout.b1, qout.b2, no_rs, cnt));
+                HIPCHK(c, launch_trace(c, false, nb, stream, qout.rays, qout.stride, qout.count, qout.seg, 0, qout.prim,
+                                       qout.t, qout.b1, qout.b2, no_rs, cnt));
                 cur ^= 1;
             }
         }

@@ -86,8 +86,20 @@ struct __attribute__((aligned(16))) GTri {    // 80 B; p1 and the two edges of t
     double _pad;
 };
 
+// Top-of-tree record staged in LDS by k_trace_top (pt_kernels.hip): a GNode whose padding holds
+// the references of its two children.  ref >= 0: index into DScene::nodes; ref < 0: LDS slot ~ref.
+struct __attribute__((aligned(16))) TopNode {   // 64 B
+    double bmin[3];
+    double bmax[3];
+    int32_t offset;
+    int32_t nprim_axis;
+    int32_t ref0, ref1;  // first (idx+1) and second (offset) child
+};
+
 struct DScene {
     const GNode *nodes;
+    const TopNode *top;        // the first n_top nodes in breadth-first order, or nullptr
+    int32_t n_top, _pad0;
     const GTri *tris;
     const double *tri_verts;   // [n_tris][9] p1,p2,p3 for shading geometry
     const int32_t *tri_mat;

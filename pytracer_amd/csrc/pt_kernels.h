@@ -94,6 +94,11 @@ hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, co
                            long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                            double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 int pt_trace_occupancy(bool any, int stack);
+// the same trace with the first sc.n_top breadth-first nodes staged in LDS (1024-thread workgroups)
+hipError_t pt_launch_trace_top(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                               long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
+                               double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
+size_t pt_trace_top_lds(int stack, int n_top);
 hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, const Queue &q,
                             const PathState &st, unsigned long long *counters);
 hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,

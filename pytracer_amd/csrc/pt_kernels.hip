@@ -187,6 +187,168 @@ __global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, c
     if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
 }
 
+// ---- top of the tree in LDS ---------------------------------------------------------------
+// k_trace_top: one 1024-thread workgroup per CU keeps the first n_top nodes of the tree in
+// breadth-first order (every ray walks them; ~45 % of all node visits on the head mesh) in LDS
+// next to the per-lane stacks, so those visits are ds_read_b128 (128 B/clk/CU, no TA, no L1 tag
+// look-ups) instead of four 64-lane vector loads each.  References on the stack and in the
+// staged records say where a node lives (TopNode, pt_device.h); the visit sequence, every
+// comparison and every counter are those of traverse<>.
+#define PT_TOP_BLOCK 1024
+
+template <bool ANY>
+__device__ __forceinline__ int traverse_top(const DScene &sc, const TopNode *top, Ray &r, int *stack, double &b1o,
+                                            double &b2o, unsigned &nvis, unsigned &ntri) {
+    int result = ANY ? 0 : -1;
+    if (sc.n_nodes == 0) return result;
+    const double invx = 1.0 / r.d.x, invy = 1.0 / r.d.y, invz = 1.0 / r.d.z;
+    const bool negx = r.d.x < 0.0, negy = r.d.y < 0.0, negz = r.d.z < 0.0;
+    int todo_idx = 0, ref = ~0;   // the root is slot 0
+    for (;;) {
+        double2 n0, n1, n2;
+        int offset, nprim_axis, ref0, ref1;
+        if (ref < 0) {
+            const double2 *q = reinterpret_cast<const double2 *>(top + ~ref);
+            n0 = q[0]; n1 = q[1]; n2 = q[2];
+            const int4 m = *reinterpret_cast<const int4 *>(&q[3]);
+            offset = m.x; nprim_axis = m.y; ref0 = m.z; ref1 = m.w;
+        } else {
+            const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + ref);
+            n0 = q[0]; n1 = q[1]; n2 = q[2];
+            const int2 m = *reinterpret_cast<const int2 *>(&q[3]);
+            offset = m.x; nprim_axis = m.y; ref0 = ref + 1; ref1 = m.x;
+        }
+        nvis++;
+        double tmin = ((negx ? n1.y : n0.x) - r.o.x) * invx;
+        double tmax = ((negx ? n0.x : n1.y) - r.o.x) * invx;
+        double tmin_y = ((negy ? n2.x : n0.y) - r.o.y) * invy;
+        double tmax_y = ((negy ? n0.y : n2.x) - r.o.y) * invy;
+        bool hitbox = !(tmin > tmax_y || tmin_y > tmax);
+        if (hitbox) {
+            if (tmin_y > tmin) tmin = tmin_y;
+            if (tmax_y < tmax) tmax = tmax_y;
+            double tmin_z = ((negz ? n2.y : n1.x) - r.o.z) * invz;
+            double tmax_z = ((negz ? n1.x : n2.y) - r.o.z) * invz;
+            hitbox = !(tmin > tmax_z || tmin_z > tmax);
+            if (hitbox) {
+                if (tmin_z > tmin) tmin = tmin_z;
+                if (tmax_z < tmax) tmax = tmax_z;
+                hitbox = (tmin < r.maxt) && (tmax > r.mint);
+            }
+        }
+        if (hitbox) {
+            const int nprim = nprim_axis & 0xFFFF;
+            if (nprim > 0) {
+                for (int i = 0; i < nprim; i++) {
+                    double t, b1, b2;
+                    ntri++;
+                    if (tri_test(sc.tris + offset + i, r, t, b1, b2)) {
+                        if (ANY) return 1;
+                        result = offset + i;
+                        b1o = b1; b2o = b2;
+                        r.maxt = t;
+                    }
+                }
+                if (todo_idx == 0) break;
+                ref = stack[(--todo_idx) * PT_TOP_BLOCK];
+            } else {
+                const int axis = nprim_axis >> 16;
+                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
+                stack[(todo_idx++) * PT_TOP_BLOCK] = neg ? ref0 : ref1;
+                ref = neg ? ref1 : ref0;
+            }
+        } else {
+            if (todo_idx == 0) break;
+            ref = stack[(--todo_idx) * PT_TOP_BLOCK];
+        }
+    }
+    return result;
+}
+
+template <bool ANY>
+__global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_top(DScene sc, const double *__restrict__ rays, long stride,
+                                                            const int *__restrict__ seg_counts, long seg, int n_val,
+                                                            int *__restrict__ out_prim, double *__restrict__ out_t,
+                                                            double *__restrict__ out_b1, double *__restrict__ out_b2,
+                                                            ShadowResolve rs, unsigned long long *counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    TopNode *top = reinterpret_cast<TopNode *>(s_mem);
+    int *stack = reinterpret_cast<int *>(s_mem + (size_t)sc.n_top * sizeof(TopNode)) + threadIdx.x;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(sc.top);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_mem);
+        for (int k = threadIdx.x; k < sc.n_top * 4; k += PT_TOP_BLOCK) dst[k] = src[k];
+    }
+    __syncthreads();
+    unsigned nvis = 0, ntri = 0, nray = 0;
+    auto one = [&](long i) {
+        Ray r;
+        r.o = mk3(rays[i], rays[stride + i], rays[2 * stride + i]);
+        r.d = mk3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
+        r.mint = rays[6 * stride + i];
+        r.maxt = rays[7 * stride + i];
+        double b1 = 0., b2 = 0.;
+        const int res = traverse_top<ANY>(sc, top, r, stack, b1, b2, nvis, ntri);
+        if (out_prim) out_prim[i] = res;
+        if (!ANY) {
+            if (out_t) out_t[i] = r.maxt;
+            if (out_b1) out_b1[i] = b1;
+            if (out_b2) out_b2[i] = b2;
+        } else if (rs.L && res == 0) {
+            const int slot = rs.slot[i];
+            unsafeAtomicAdd(rs.L + slot, rs.c[i]);
+            unsafeAtomicAdd(rs.L + rs.lstride + slot, rs.c[rs.cstride + i]);
+            unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + i]);
+        }
+        nray++;
+    };
+    if (seg_counts) {
+        const int lane = threadIdx.x & 63;
+        const int wave = (int)((blockIdx.x * PT_TOP_BLOCK + threadIdx.x) >> 6);
+        const int nsub = (int)((gridDim.x * (PT_TOP_BLOCK / 64)) / PT_SEG);
+        const int r = wave % PT_SEG, sub = wave / PT_SEG;
+        if (sub < nsub) {
+            const int n = seg_counts[r];
+            const long first = (long)r * seg;
+            for (int k = sub * 64 + lane; k < n; k += nsub * 64) one(first + k);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * PT_TOP_BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * PT_TOP_BLOCK) one(i);
+    }
+    if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
+}
+
+// LDS bytes of k_trace_top for a tree that needs `stack` todo levels and stages n_top nodes
+size_t pt_trace_top_lds(int stack, int n_top) {
+    return (size_t)n_top * sizeof(TopNode) + (size_t)stack * PT_TOP_BLOCK * sizeof(int);
+}
+
+hipError_t pt_launch_trace_top(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                               long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
+                               double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
+    static bool attr_set[2] = {false, false};
+    const size_t lds = pt_trace_top_lds(stack, sc.n_top);
+    if (!attr_set[any ? 1 : 0]) {
+        hipError_t e = any ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_top<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_top<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[any ? 1 : 0] = true;
+    }
+    if (seg_counts) {   // whole sets of PT_SEG waves
+        const int per = PT_SEG / (PT_TOP_BLOCK / 64);
+        grid = ((grid + per - 1) / per) * per;
+    }
+    if (any)
+        hipLaunchKernelGGL((k_trace_top<true>), dim3(grid), dim3(PT_TOP_BLOCK), lds, stream, sc, rays, stride, seg_counts,
+                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    else
+        hipLaunchKernelGGL((k_trace_top<false>), dim3(grid), dim3(PT_TOP_BLOCK), lds, stream, sc, rays, stride, seg_counts,
+                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    return hipGetLastError();
+}
+
 template <bool ANY>
 static hipError_t launch_trace_t(int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
                                  long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,

@@ -104,6 +104,42 @@ def test_intersect_soups(torch_cuda, ctx, golden_dir, name):
     assert np.array_equal(gp, op) and np.array_equal(gt, ot)
 
 
+def test_top_of_tree_kernel_is_bitwise_the_same(torch_cuda, golden_dir, head):
+    """k_trace_top (first breadth-first nodes staged in LDS, PT_TRACE_TOP=1; off by default because it
+    measured slower) walks the same nodes in the same order: outputs and visit counts equal the oracle's."""
+    import oracle_lib as O
+    from pytracer_amd._lib import Context
+    os.environ['PT_TRACE_TOP'] = '1'
+    try:
+        c = Context(0)
+    finally:
+        del os.environ['PT_TRACE_TOP']
+    try:
+        cases = [(head[1], head[2], rays_from_log(load(golden_dir, 'head_path_32x32x4.npz')['log_rays']))]
+        for name in ('bvh_soup2000.npz', 'bvh_soup500dup.npz'):
+            d = load(golden_dir, name)
+            flat = pa.flat_scene_from_npz(d)
+            cases.append((flat, O.OracleScene(flat), np.ascontiguousarray(d['rays'].T)))
+        for flat, osc, rays in cases:
+            c.upload(flat)
+            for any_hit in (False, True):
+                sg, so = A.pt_stats(), A.pt_stats()
+                gp, gt, gb1, gb2 = gpu_intersect(torch_cuda, c, rays, any_hit, stats=sg)
+                op, ot, ob1, ob2 = osc.intersect(rays, any_hit=any_hit, stats=so)
+                assert np.array_equal(gp, op)
+                if not any_hit:
+                    assert np.array_equal(gt, ot) and np.array_equal(gb1, ob1) and np.array_equal(gb2, ob2)
+                assert sg.as_dict() == so.as_dict()
+        # and through a whole render
+        d = load(golden_dir, 'head_path_32x32x4.npz')
+        c.upload(head[1])
+        acc, L, _ = gpu_render(torch_cuda, c, d, d['sub'], d['spp'], pa.integrator_desc(A.PT_INTEG_PATH, 5, True),
+                               table=d['samples'])
+        assert rel_err(L, d['L']) < REF_RTOL
+    finally:
+        c.close()
+
+
 def test_intersect_edge_cases(torch_cuda, ctx, golden_dir, head):
     """Empty batch, a single ray, a ragged (non multiple of 64/256) batch, zero-length maxt."""
     _, flat, osc = head
