@@ -32,7 +32,8 @@ struct pt_ctx {
     PathState st;
     int use_top;             // PT_TRACE_TOP=1: stage the top of the tree in LDS (k_trace_top); measured 5 % slower
                              // than the plain kernel on the head mesh, so off by default
-    int *d_counts;           // [3][PT_SEG]: region fill counters of q0, q1 and the shadow queue
+    int *hit_idx;            // [cap] hit list of the current closest-hit trace (HitList::idx)
+    int *d_counts;           // [4][PT_SEG]: region fill counters of q0, q1, the shadow queue and the hit list
     int trace_occ[2];        // resident blocks/CU of the closest / any trace kernels (0 = not queried)
     RenderConst *d_rc;
     unsigned long long *d_counters;
@@ -96,7 +97,7 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    CREATE_CHK(hipMalloc((void **)&c->d_counts, 3 * PT_SEG * sizeof(int)));
+    CREATE_CHK(hipMalloc((void **)&c->d_counts, 4 * PT_CNT_BLOCK * sizeof(int)));
     c->use_top = 0;
     if (const char *e = getenv("PT_TRACE_TOP")) c->use_top = atoi(e);
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
@@ -425,8 +426,9 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // carve the wavefront workspace: two ray queues, the shadow queue (all segmented, pt_kernels.h)
 // and the path state.  `paths` = paths in flight, spv = shadow rays one shaded entry can emit.
-static int ensure_workspace(pt_ctx *c, long paths, int spv) {
-    const long seg = 64 * ((((paths + 63) / 64) + PT_SEG - 1) / PT_SEG);   // whole 64-entry chunks per region
+static int ensure_workspace(pt_ctx *c, long paths, int spv, int gshift) {
+    const long gsz = 64l << gshift;                                         // whole groups per region (seg_entry)
+    const long seg = gsz * ((((paths + gsz - 1) / gsz) + PT_SEG - 1) / PT_SEG);
     const long cap = seg * PT_SEG, sh_cap = cap * spv;
     if (c->ws && c->cap == cap && c->sh_cap == sh_cap) return PT_OK;
     if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; }
@@ -445,6 +447,7 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv) {
     size_t off_ss = need(sh_cap * sizeof(int));
     size_t off_T = need(3 * cap * sizeof(double)), off_L = need(3 * cap * sizeof(double));
     size_t off_img = need(2 * cap * sizeof(double));
+    size_t off_hit = need(cap * sizeof(int));
     HIPCHK(c, hipMalloc(&c->ws, bytes));
     char *b = (char *)c->ws;
     for (int k = 0; k < 2; k++) {
@@ -452,12 +455,13 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv) {
         q.rays = (double *)(b + off_q[k][0]); q.stride = cap; q.seg = seg;
         q.slot = (int *)(b + off_q[k][1]); q.prim = (int *)(b + off_q[k][2]);
         q.t = (double *)(b + off_q[k][3]); q.b1 = (double *)(b + off_q[k][4]); q.b2 = (double *)(b + off_q[k][5]);
-        q.count = c->d_counts + k * PT_SEG;
+        q.count = c->d_counts + k * PT_CNT_BLOCK;
     }
     c->sh.rays = (double *)(b + off_sr); c->sh.c = (double *)(b + off_sc); c->sh.slot = (int *)(b + off_ss);
-    c->sh.stride = sh_cap; c->sh.seg = seg * spv; c->sh.count = c->d_counts + 2 * PT_SEG;
+    c->sh.stride = sh_cap; c->sh.seg = seg * spv; c->sh.count = c->d_counts + 2 * PT_CNT_BLOCK;
     c->st.T = (double *)(b + off_T); c->st.L = (double *)(b + off_L); c->st.img = (double *)(b + off_img);
     c->st.stride = cap;
+    c->hit_idx = (int *)(b + off_hit);
     c->cap = cap; c->sh_cap = sh_cap; c->ws_bytes = bytes;
     return PT_OK;
 }
@@ -536,7 +540,11 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     batch = std::min(batch, total);
     batch = (batch + 63) & ~63l;
     const int spv = ig->kind == PT_INTEG_DIRECT ? std::max(c->shadow_per_vertex_direct, 1) : 1;
-    int rc = ensure_workspace(c, batch, spv);
+    // chunk-group size of the segmented queues: up to 64 chunks (the 4096-entry sort window), fewer
+    // for small batches so that every region still gets several groups
+    int gshift = 0;
+    while (gshift < 6 && ((batch / 64) >> (gshift + 1)) >= 4 * PT_SEG) gshift++;
+    int rc = ensure_workspace(c, batch, spv, gshift);
     if (rc != PT_OK) return rc;
 
     HIPCHK(c, hipMemcpyAsync(c->d_rc, &h, sizeof(h), hipMemcpyHostToDevice, stream));
@@ -552,6 +560,14 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     else levels = c->has_spec_reflect ? std::max(ig->max_depth, 1) : 1;
 
     const ShadowResolve no_rs = {nullptr, 0, nullptr, nullptr, 0};
+    auto hit_list = [&](int level) {
+        HitList hl{};
+        hl.idx = c->hit_idx; hl.count = c->d_counts + 3 * PT_CNT_BLOCK;
+        hl.T = c->st.T; hl.L = c->st.L; hl.pstride = c->st.stride;
+        memcpy(hl.le, c->sc.le_sum, sizeof(hl.le));
+        hl.add_escape = level > 0;
+        return hl;
+    };
     c->ev_used = 0;
     for (long base = 0; base < total; base += batch) {
         const int nb = (int)std::min(batch, total - base);
@@ -559,7 +575,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         const int gs = (int)std::max<long>(1, std::min<long>((nb + PT_BLOCK - 1) / PT_BLOCK, (long)c->n_cu * 4));
         {
             StageTimer tm(c, stream, STAGE_RAYGEN);
-            HIPCHK(c, pt_launch_raygen(g, stream, c->d_rc, base, nb, c->q[0], c->st, cnt));
+            HIPCHK(c, pt_launch_raygen(g, stream, c->d_rc, base, nb, gshift, c->q[0], c->st, cnt));
         }
         if (ig->pretest) {   // renderer.py:168: same hit flag as the closest-hit pass below
             StageTimer tm(c, stream, STAGE_TRACE_ANY);
@@ -574,11 +590,14 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         int cur = 0;
         for (int level = 0; level < levels; level++) {
             Queue &qin = c->q[cur], &qout = c->q[cur ^ 1];
-            HIPCHK(c, hipMemsetAsync(qout.count, 0, PT_SEG * sizeof(int), stream));
-            HIPCHK(c, hipMemsetAsync(c->sh.count, 0, PT_SEG * sizeof(int), stream));
+            HIPCHK(c, hipMemsetAsync(qout.count, 0, PT_CNT_BLOCK * sizeof(int), stream));
+            HIPCHK(c, hipMemsetAsync(c->sh.count, 0, PT_CNT_BLOCK * sizeof(int), stream));
             {
                 StageTimer tm(c, stream, STAGE_SHADE);
-                HIPCHK(c, pt_launch_shade(ig->kind, gs, stream, c->sc, c->d_rc, base, level, qin, qout, c->sh, c->st));
+                HIPCHK(c, hipMemsetAsync(c->d_counts + 3 * PT_CNT_BLOCK, 0, PT_CNT_BLOCK * sizeof(int), stream));
+                HIPCHK(c, pt_launch_list_hits(gs * 2, stream, qin, hit_list(level)));
+                HIPCHK(c, pt_launch_shade(ig->kind, gs, stream, c->sc, c->d_rc, base, level, qin, hit_list(level), qout,
+                                          c->sh, c->st));
             }
             ShadowResolve rs = {c->sh.c, c->sh.stride, c->sh.slot, c->st.L, c->st.stride};
             {
@@ -587,13 +606,13 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
                                        0, nullptr, nullptr, nullptr, nullptr, rs, cnt));
             }
             if (getenv("PT_DEBUG_LEVELS") && base == 0) {   // debugging aid: queue sizes per level (syncs)
-                int h[3 * PT_SEG];
-                long tot[3] = {0, 0, 0};
-                (void)hipMemcpyAsync(h, c->d_counts, sizeof(h), hipMemcpyDeviceToHost, stream);
+                std::vector<int> h(4 * PT_CNT_BLOCK);
+                long tot[4] = {0, 0, 0, 0};
+                (void)hipMemcpyAsync(h.data(), c->d_counts, h.size() * sizeof(int), hipMemcpyDeviceToHost, stream);
                 (void)hipStreamSynchronize(stream);
-                for (int k = 0; k < 3 * PT_SEG; k++) tot[k / PT_SEG] += h[k];
-                fprintf(stderr, "[pt] level %d: in %ld, continuation %ld, shadow %ld\n", level, tot[cur], tot[cur ^ 1],
-                        tot[2]);
+                for (int k = 0; k < 4 * PT_CNT_BLOCK; k += PT_CNT_STRIDE) tot[k / PT_CNT_BLOCK] += h[k];
+                fprintf(stderr, "[pt] level %d: in %ld (hits %ld), continuation %ld, shadow %ld\n", level, tot[cur], tot[3],
+                        tot[cur ^ 1], tot[2]);
             }
             if (level + 1 < levels) {
                 StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);

@@ -31,6 +31,11 @@ enum {
 // one L2 word (~88 atomics/us, MI355X_MICROARCH.md) and cost more than the shading itself.
 // Grids of kernels that walk a segmented queue are multiples of PT_SEG_BLOCKS workgroups.
 #define PT_SEG 64
+// Region r's fill counter is element r * PT_CNT_STRIDE of a counter block: one 128-byte line each.
+// Packed, the 64 counters shared two lines and every append in the chip serialised on them in L2
+// (k_list_hits: 4.9 ms for 67 M entries packed).
+#define PT_CNT_STRIDE 32
+#define PT_CNT_BLOCK (PT_SEG * PT_CNT_STRIDE)
 #define PT_SEG_BLOCKS (PT_SEG / (PT_BLOCK / 64))
 
 // ray queue: traced rays and (after K3) their hit records, plus the path slot they belong to
@@ -42,7 +47,7 @@ struct Queue {
     int *prim;      // [stride] closest-hit primitive or -1
     double *t;      // [stride] ray.maxt after traversal
     double *b1, *b2;
-    int *count;     // [PT_SEG] device counters
+    int *count;     // [PT_SEG] device counters, PT_CNT_STRIDE apart
 };
 
 // shadow-ray queue (segmented the same way) with the contribution each ray carries if unoccluded
@@ -53,6 +58,17 @@ struct ShadowQueue {
     long seg;       // = shadow rays per entry x Queue::seg
     int *slot;
     int *count;     // [PT_SEG]
+};
+
+// hits of a closest-hit trace over a render queue, listed per region (pt_kernels.hip k_list_hits)
+struct HitList {
+    int *idx;          // [stride] region-local entry numbers, dense from region * seg; nullptr = off
+    int *count;        // [PT_SEG]
+    const double *T;   // path state, for the rays that escaped
+    double *L;
+    long pstride;
+    double le[3];      // Σ light.le
+    int add_escape;    // level > 0: a miss adds T * le to L[slot]
 };
 
 struct ShadowResolve {
@@ -99,10 +115,11 @@ hipError_t pt_launch_trace_top(bool any, int stack, int grid, hipStream_t stream
                                long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                                double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 size_t pt_trace_top_lds(int stack, int n_top);
-hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, const Queue &q,
-                            const PathState &st, unsigned long long *counters);
+hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, int gshift,
+                            const Queue &q, const PathState &st, unsigned long long *counters);
+hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, const HitList &hl);
 hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,
-                           int level, const Queue &qin, const Queue &qout, const ShadowQueue &sh,
+                           int level, const Queue &qin, const HitList &hl, const Queue &qout, const ShadowQueue &sh,
                            const PathState &st);
 hipError_t pt_launch_splat(hipStream_t stream, const RenderConst *rc, const pt_tile &tile, const pt_film_desc &fm,
                            long base, int nb, const PathState &st, double *film, double *sample_L,

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, c
         const int nsub = (int)((gridDim.x * (PT_BLOCK / 64)) / PT_SEG);
         const int r = wave % PT_SEG, sub = wave / PT_SEG;
         if (sub < nsub) {
-            const int n = seg_counts[r];
+            const int n = seg_counts[r * PT_CNT_STRIDE];
             const long first = (long)r * seg;
             for (int k = sub * 64 + lane; k < n; k += nsub * 64) {
                 trace_one<ANY>(sc, rays, stride, first + k, s_stack + threadIdx.x, out_prim, out_t, out_b1, out_b2, rs,
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_top(DScene sc, const dou
         const int nsub = (int)((gridDim.x * (PT_TOP_BLOCK / 64)) / PT_SEG);
         const int r = wave % PT_SEG, sub = wave / PT_SEG;
         if (sub < nsub) {
-            const int n = seg_counts[r];
+            const int n = seg_counts[r * PT_CNT_STRIDE];
             const long first = (long)r * seg;
             for (int k = sub * 64 + lane; k < n; k += nsub * 64) one(first + k);
         }
@@ -476,14 +476,31 @@ __device__ inline void concentric_sample_disk(double u1, double u2, double &ox, 
     ox = r * cos(theta); oy = r * sin(theta);
 }
 
-__global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restrict__ rcp, long base, int nb,
+// Where camera sample i of a batch goes in the segmented queue (pt_kernels.h): samples travel in
+// groups of G = 2^gshift 64-sample chunks (consecutive pixels: the waves that serve a region work
+// on neighbouring pixels at any one time: +6 % on the whole render over a chunk-interleaved mapping);
+// group g of round j = g / PT_SEG goes to region (g + 17 j) % PT_SEG — a rotation per round, so
+// every region receives one group per round (the capacity bound) and image columns are spread
+// over all regions (the load balance).
+__device__ __forceinline__ long seg_entry(int i, int gshift, long seg) {
+    const int ch = i >> 6, g = ch >> gshift, j = g / PT_SEG;
+    const int r = (g + 17 * j) % PT_SEG;
+    return (long)r * seg + ((((long)j << gshift) + (ch & ((1 << gshift) - 1))) << 6) + (i & 63);
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restrict__ rcp, long base, int nb, int gshift,
                                                      Queue q, PathState st, unsigned long long *counters) {
     const RenderConst &rc = *rcp;
     const int i = blockIdx.x * PT_BLOCK + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < PT_SEG) {
-        // fill level of every region, known in closed form
-        const int r = threadIdx.x, nfull = nb >> 6, rem = nb & 63;
-        q.count[r] = 64 * (nfull / PT_SEG + (r < nfull % PT_SEG ? 1 : 0)) + (r == nfull % PT_SEG ? rem : 0);
+        // fill level of every region, in closed form: whole groups, except the batch's last one
+        const int r = threadIdx.x, gsz = 64 << gshift;
+        const int ngroups = (nb + gsz - 1) / gsz, J = ngroups / PT_SEG, R = ngroups % PT_SEG;
+        const int b = ((r - 17 * J) % PT_SEG + PT_SEG) % PT_SEG;      // position of region r in the partial round
+        int cnt = (J + (b < R ? 1 : 0)) * gsz;
+        const int gl = ngroups - 1, jl = gl / PT_SEG;
+        if (r == (gl + 17 * jl) % PT_SEG) cnt -= ngroups * gsz - nb;
+        q.count[r * PT_CNT_STRIDE] = cnt;
     }
     if (i >= nb) return;
     int px, py, si;
@@ -515,11 +532,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
     }
     o = xf4_point(rc.cam.c2w, o);
     d = xf_vec(rc.cam.c2w, d);
-    // sample i of the batch goes to region (i/64) % PT_SEG of the segmented queue, behind the
-    // earlier 64-sample chunks of the same residue
     const long S = q.stride;
-    const int ch = i >> 6;
-    const long e = (long)(ch % PT_SEG) * q.seg + (long)(ch / PT_SEG) * 64 + (i & 63);
+    const long e = seg_entry(i, gshift, q.seg);
     q.rays[e] = o.x; q.rays[S + e] = o.y; q.rays[2 * S + e] = o.z;
     q.rays[3 * S + e] = d.x; q.rays[4 * S + e] = d.y; q.rays[5 * S + e] = d.z;
     q.rays[6 * S + e] = 0.; q.rays[7 * S + e] = __builtin_inf();
@@ -567,7 +581,7 @@ __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, con
 
 __device__ __forceinline__ void push_shadow(const ShadowQueue &sh, int region, bool pred, const Ray &r, d3 c,
                                             int slot) {
-    long pos = wave_append(pred, sh.count + region);
+    long pos = wave_append(pred, sh.count + region * PT_CNT_STRIDE);
     if (pos >= 0) {
         pos += (long)region * sh.seg;
         const long S = sh.stride;
@@ -590,7 +604,8 @@ __device__ __forceinline__ void push_shadow(const ShadowQueue &sh, int region, b
 #endif
 template <int KIND>
 __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
-                                                    int level, Queue qin, Queue qout, ShadowQueue sh, PathState st) {
+                                                    int level, Queue qin, HitList hl, Queue qout, ShadowQueue sh,
+                                                    PathState st) {
     const RenderConst &rc = *rcp;
     // wave w serves region w % PT_SEG of the input queue and appends to the SAME region of both
     // output queues (pt_kernels.h "segmented queues")
@@ -598,23 +613,17 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
     const int nsub = (int)((gridDim.x * (PT_BLOCK / 64)) / PT_SEG);
     const int region = wave % PT_SEG, sub = wave / PT_SEG;
     if (sub >= nsub) return;
-    const int n = qin.count[region];
+    const int n = hl.count[region * PT_CNT_STRIDE];     // the entries of this region whose ray hit something (list_hit)
     const int nloop = (n + 63) & ~63;   // whole waves stay convergent for the ballots
     const long first = (long)region * qin.seg;
     for (int k = sub * 64 + (int)(threadIdx.x & 63); k < nloop; k += nsub * 64) {
         const bool live = k < n;
-        const long i = first + k;
+        const long i = first + (live ? hl.idx[first + k] : 0);
         int slot = 0, prim = -1;
         if (live) { slot = qin.slot[i]; prim = qin.prim[i]; }
         const long P = st.stride, S = qin.stride;
         d3 T = mk3(0, 0, 0);
         if (live) T = mk3(st.T[slot], st.T[P + slot], st.T[2 * P + slot]);
-        if (live && prim < 0 && level > 0) {
-            // escaped continuation ray: Σ light.le(ray) (renderer.py:66-68 / path.py:130-135)
-            st.L[slot] += T.x * sc.le_sum[0];
-            st.L[P + slot] += T.y * sc.le_sum[1];
-            st.L[2 * P + slot] += T.z * sc.le_sum[2];
-        }
         const bool hit = live && prim >= 0;
         Ray ray;
         Vertex vx;
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                 }
             }
         }
-        long pos = wave_append(cont, qout.count + region);
+        long pos = wave_append(cont, qout.count + region * PT_CNT_STRIDE);
         if (pos >= 0) {
             pos += (long)region * qout.seg;
             const long SO = qout.stride;
@@ -732,20 +741,55 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
     }
 }
 
-hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, const Queue &q,
-                            const PathState &st, unsigned long long *counters) {
-    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(PT_BLOCK), 0, stream, rc, base, nb, q, st, counters);
+hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, int gshift,
+                            const Queue &q, const PathState &st, unsigned long long *counters) {
+    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(PT_BLOCK), 0, stream, rc, base, nb, gshift, q, st, counters);
+    return hipGetLastError();
+}
+
+// K3b, after a closest-hit trace of a render queue: an escaped continuation ray adds T * Σ light.le
+// (renderer.py:66-68 / path.py:130-135), and the entries that hit something are listed per region
+// (wave ballot + one atomic per wave) so that k_shade walks hits only.  From the second bounce on
+// ~70 % of the head-mesh rays escape; shading them in place left most lanes of every wave idle
+// (shade 25 -> 18 ms per step).  A pass of its own, ~0.1 ms per million entries: inside k_trace the
+// extra live state spilled at the 80-VGPR budget and cost more than it saved.
+__global__ __launch_bounds__(PT_BLOCK) void k_list_hits(Queue q, HitList hl) {
+    const int wave = (int)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6);
+    const int nsub = (int)((gridDim.x * (PT_BLOCK / 64)) / PT_SEG);
+    const int region = wave % PT_SEG, sub = wave / PT_SEG;
+    if (sub >= nsub) return;
+    const int n = q.count[region * PT_CNT_STRIDE];
+    const int nloop = (n + 63) & ~63;
+    const long first = (long)region * q.seg;
+    for (int k = sub * 64 + (int)(threadIdx.x & 63); k < nloop; k += nsub * 64) {
+        const bool live = k < n;
+        const int prim = live ? q.prim[first + k] : -1;
+        if (live && prim < 0 && hl.add_escape) {
+            const int slot = q.slot[first + k];
+            const long P = hl.pstride;
+            hl.L[slot] += hl.T[slot] * hl.le[0];
+            hl.L[P + slot] += hl.T[P + slot] * hl.le[1];
+            hl.L[2 * P + slot] += hl.T[2 * P + slot] * hl.le[2];
+        }
+        const int pos = wave_append(prim >= 0, hl.count + region * PT_CNT_STRIDE);
+        if (pos >= 0) hl.idx[first + pos] = k;
+    }
+}
+
+hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, const HitList &hl) {
+    grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
+    hipLaunchKernelGGL(k_list_hits, dim3(grid), dim3(PT_BLOCK), 0, stream, q, hl);
     return hipGetLastError();
 }
 
 hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,
-                           int level, const Queue &qin, const Queue &qout, const ShadowQueue &sh,
+                           int level, const Queue &qin, const HitList &hl, const Queue &qout, const ShadowQueue &sh,
                            const PathState &st) {
     grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
     if (kind == PT_INTEG_DIRECT)
-        hipLaunchKernelGGL((k_shade<PT_INTEG_DIRECT>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, qout, sh, st);
+        hipLaunchKernelGGL((k_shade<PT_INTEG_DIRECT>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st);
     else
-        hipLaunchKernelGGL((k_shade<PT_INTEG_PATH>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, qout, sh, st);
+        hipLaunchKernelGGL((k_shade<PT_INTEG_PATH>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st);
     return hipGetLastError();
 }
 

@@ -71,19 +71,18 @@ def main():
     # the same secondary rays regrouped: does direction coherence inside a wave pay?
     octant = ((sec[3] < 0).long() * 4 + (sec[4] < 0).long() * 2 + (sec[5] < 0).long())
     M = sec.shape[1]
-    idx = torch.arange(M, device=dev)
+    idx = torch.arange(N, device=dev)[hit]            # camera-sample ordinal of every secondary ray
+    pix = idx // spp
+    py_, px_ = pix // n, pix % n
     sets = [('camera', cam), ('random-secondary', sec), ('to-light', sh)]
-    for win in (4096, 65536, M):
-        key = (idx // win) * 8 + octant
-        order = torch.argsort(key, stable=True)
-        sets.append(('sec octant/%d' % win, sec[:, order].contiguous()))
-    # finer direction bins (octant x 4 x 4 by the two minor components), windows of 65536
+    sets.append(('sec octant/all', sec[:, torch.argsort(octant, stable=True)].contiguous()))
     ax = sec[3:6].abs()
     fine = octant * 16 + (ax[0] * 3.999).long().clamp(0, 3) * 4 + (ax[1] * 3.999).long().clamp(0, 3)
-    for win in (65536, M):
-        order = torch.argsort((idx // win) * 128 + fine, stable=True)
-        sets.append(('sec fine128/%d' % win, sec[:, order].contiguous()))
-    sets.append(('sec shuffled', sec[:, torch.randperm(M, device=dev, generator=g)].contiguous()))
+    for T in (8, 16, 32, 64):
+        tile = (py_ // T) * (n // T) + (px_ // T)
+        sets.append(('sec tile%d,octant' % T, sec[:, torch.argsort(tile * 8 + octant, stable=True)].contiguous()))
+        sets.append(('sec tile%d,fine128' % T, sec[:, torch.argsort(tile * 128 + fine, stable=True)].contiguous()))
+        sets.append(('sec octant,tile%d' % T, sec[:, torch.argsort(octant * (tile.max() + 1) + tile, stable=True)].contiguous()))
     torch.cuda.synchronize()
     for name, rays in sets:
         for any_hit in (False, True):
