@@ -300,8 +300,10 @@ def flatten_scene(scene):
         if type(sh).__name__ != 'Triangle':
             raise NotImplementedError('only triangles may be in the BVH (got %s)' % type(sh).__name__)
         m = sh.mesh
-        if m.uvs is not None or m.n is not None or m.s is not None or m.alphaTexture is not None:
-            raise NotImplementedError('meshes with uv / N / S / alpha are outside the supported hot path')
+        # shading geometry is the geometric one unless the mesh has BOTH N and S (triangle.py:325):
+        # LoopSubdiv meshes carry N only and shade like plain meshes
+        if m.uvs is not None or (m.n is not None and m.s is not None) or m.alphaTexture is not None:
+            raise NotImplementedError('meshes with uv / N+S shading frames / alpha are outside the supported hot path')
         if getattr(pr, 'areaLight', None) is not None:
             raise NotImplementedError('emissive primitives are outside the supported hot path')
         for k in range(3):

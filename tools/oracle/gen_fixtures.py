@@ -91,7 +91,8 @@ def dump_scene(scene, camera=None):
     for i, pr in enumerate(agg.primitives):
         sh = pr.shape
         m = sh.mesh
-        assert m.uvs is None and m.n is None and m.s is None and m.alphaTexture is None
+        # shading geometry == geometric unless the mesh has BOTH N and S (triangle.py:325)
+        assert m.uvs is None and (m.n is None or m.s is None) and m.alphaTexture is None
         for k in range(3):
             verts[i, 3 * k:3 * k + 3] = m.p[m.vertexIndex[sh.v + k]]
         flip[i] = int(bool(sh.ro) ^ bool(sh.transform_swaps_handedness))
@@ -508,7 +509,69 @@ def gen_c4mini():
             np.bincount(d['log_sl_light'], minlength=3)))
 
 
-ALL = dict(c4mini=gen_c4mini, scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
+def gen_c2():
+    """C2 (BASELINE.json configs[1]): examples/head_loop.py — the head mesh after 3 levels of Loop
+    subdivision (177 666 triangles), 512x512, 4x4 spp, DirectLightingIntegrator.  Importing the example
+    runs the reference's subdivision and its Python BVH build (minutes).  The fixture holds the
+    subdivided mesh (the builder's INPUT), digests of the reference's tree (352 k nodes are too big to
+    commit), reference-traced rays, and a reference render of a small window."""
+    import hashlib
+    t = time.time()
+    import examples.head_loop as model
+    print('c2: scene built by the reference in %.1fs' % (time.time() - t), flush=True)
+    bvh = model.scene.aggregate
+    sc = dump_scene(model.scene)
+    d = {}
+    for k in ('node_bounds', 'node_meta', 'tri_verts', 'tri_mat', 'tri_flip'):
+        d['sha256_' + k] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(sc[k]).tobytes()).digest(), np.uint8)
+    d['n_nodes'] = np.int64(len(sc['node_bounds']))
+    d['n_tris'] = np.int64(len(sc['tri_verts']))
+    for k, v in sc.items():
+        if k.startswith('mat') or k.startswith('light') or k in ('n_materials', 'n_lights'):
+            d[k] = v
+    # the meshes as the reference refined them, in the order of BVH([head, back])
+    meshes = []
+    for pr in bvh.primitives:
+        if pr.shape.mesh not in meshes:
+            meshes.append(pr.shape.mesh)
+    order = sorted(range(len(meshes)), key=lambda i: -meshes[i].ntris)      # head first, backdrop second
+    for j, i in enumerate(order):
+        m = meshes[i]
+        d['mesh%d_p' % j] = np.array([np.array(p) for p in m.p], np.float64)
+        d['mesh%d_idx' % j] = np.array(m.vertexIndex, np.int32)
+        d['mesh%d_mat' % j] = np.int32(sc['tri_mat'][[k for k, pr in enumerate(bvh.primitives) if pr.shape.mesh is m][0]])
+    # reference-traced rays
+    rng = np.random.default_rng(2024)
+    nr = 300
+    o = np.array([-13., -1., -35.]) + rng.normal(0, .5, (nr, 3))
+    tgt = np.array([-3., 6., -15.]) + rng.uniform(-6, 6, (nr, 3))
+    rays = np.zeros((nr, 8))
+    rays[:, 0:3] = o
+    rays[:, 3:6] = tgt - o
+    rays[:, 7] = np.where(rng.uniform(size=nr) < .7, np.inf, 1.0)
+    prim_index = {id(p): i for i, p in enumerate(bvh.primitives)}
+    res = np.zeros((nr, 4))
+    for i in range(nr):
+        r = geo.Ray(geo.Point(*rays[i, 0:3]), geo.Vector(*rays[i, 3:6]), rays[i, 6], rays[i, 7])
+        isect = Intersection()
+        hit = bvh.intersect(r, isect)
+        r2 = geo.Ray(geo.Point(*rays[i, 0:3]), geo.Vector(*rays[i, 3:6]), rays[i, 6], rays[i, 7])
+        res[i] = (int(hit), prim_index[id(isect.primitive)] if hit else -1, r.maxt, int(bvh.intersect_p(r2)))
+    d['rays'] = rays
+    d['res'] = res
+    print('c2: %d nodes, %d tris, ray hits %d, %.1fs' % (d['n_nodes'], d['n_tris'], int(res[:, 0].sum()), time.time() - t),
+          flush=True)
+    # a window of the C2 render itself
+    w = instrumented_render(model, 512, 512, 4, 4, DirectLightingIntegrator(), seed=3, sub=(250, 262, 180, 190))
+    for k, v in w.items():
+        if not k.startswith('log_hitgeo'):
+            d[k] = v
+    np.savez_compressed(os.path.join(OUT, 'c2_head_loop.npz'), **d)
+    print('c2: window rendered, rays logged %d, sumL %.6f, total %.1fs' % (len(w['log_rays']), w['L'].sum(),
+                                                                          time.time() - t))
+
+
+ALL = dict(c2=gen_c2, c4mini=gen_c4mini, scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)
