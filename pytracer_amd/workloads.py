@@ -1,0 +1,68 @@
+"""Synthetic workloads of BASELINE.json / SURVEY.md §8(d), described without the reference.
+
+``c4_soup``: configs[3] — a soup of random triangles (BVH stress), alternating Matte / Plastic-like
+materials, one SpotLight and one sphere DiffuseAreaLight, camera at (0,0,-30) looking +z, fov 60.
+The tree is built by the native reference-exact builder (pt_bvh_build)."""
+import numpy as np
+
+from . import _abi as A
+from . import accel, host
+from .flatten import lobes_from_params
+
+
+def c4_triangles(n_tris=10 ** 6, seed=12345, edge_sigma=.05):
+    """centres U[-10,10]^3, two edge vectors N(0, 0.05^2 I) each."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-10., 10., (n_tris, 3))
+    e1 = rng.normal(0., edge_sigma, (n_tris, 3))
+    e2 = rng.normal(0., edge_sigma, (n_tris, 3))
+    return np.concatenate([c, c + e1, c + e2], axis=1)
+
+
+def _rotate_x(deg):
+    """Transform.rotate_x, transform/__init__.py:132-141."""
+    s, c = np.sin(np.deg2rad(deg)), np.cos(np.deg2rad(deg))
+    m = np.eye(4)
+    m[1, 1], m[1, 2], m[2, 1], m[2, 2] = c, -s, s, c
+    return m
+
+
+def c4_lights():
+    """SpotLight at (0,15,-25) aimed at the origin, width 30 deg, falloff 25 deg, I = 200
+    (light/light.py:162-171), and a sphere DiffuseAreaLight r = 3, emit 10, ns = 2 (light.py:484-500)."""
+    l2w = host._translate(0., 15., -25.).dot(_rotate_x(np.rad2deg(np.arctan2(15., 25.))))
+    spot = dict(kind=A.PT_LIGHT_SPOT, pos=l2w[:3, 3].copy(), intensity=np.full(3, 200.), ns=1,
+                w2l=np.linalg.inv(l2w), cos_width=np.cos(np.deg2rad(30.)), cos_falloff=np.cos(np.deg2rad(25.)))
+    o2w = host._translate(-10., 10., -20.)
+    sphere = dict(kind=A.PT_LIGHT_DIFFUSE_SPHERE, emit=np.full(3, 10.), ns=2, radius=3., o2w=o2w,
+                  w2o=np.linalg.inv(o2w), ro=False, zmin=-3., zmax=3., phimax=2. * np.pi)
+    return [spot, sphere]
+
+
+def c4_materials(n_materials=64, seed=12345):
+    """alternating Matte(Kd U[.1,.9]) / Plastic(Kd, Ks = .3, Blinn exponent U[5,100])."""
+    rng = np.random.default_rng(seed + 1)
+    lobes = []
+    for i in range(n_materials):
+        kd = rng.uniform(.1, .9, 3)
+        if i % 2 == 0:
+            lobes.append(lobes_from_params('matte', Kd=kd, sigma=0.))
+        else:
+            lobes.append(lobes_from_params('plastic', Kd=kd, Ks=np.full(3, .3), roughness=1. / rng.uniform(5., 100.)))
+    return lobes
+
+
+def c4_soup(n_tris=10 ** 6, seed=12345, n_materials=64, edge_sigma=.05):
+    """FlatScene of the C4 soup (built natively; ~1 s per million triangles)."""
+    tv = c4_triangles(n_tris, seed, edge_sigma)
+    tm = (np.arange(n_tris) % n_materials).astype(np.int32)
+    flat, _ = accel.flat_scene_from_triangles(tv, c4_materials(n_materials, seed), c4_lights(), tri_mat=tm)
+    return flat
+
+
+def c4_camera_film(x_res=1920, y_res=1080):
+    """PerspectiveCamera at (0,0,-30) looking +z, fov 60, screen window scaled to the aspect ratio;
+    Lanczos(4,4,3) film like the examples."""
+    ar = float(x_res) / float(y_res)
+    cam = host.perspective_camera(host._translate(0., 0., -30.), [-ar, ar, -1., 1.], 60., x_res, y_res)
+    return cam, host.image_film(x_res, y_res, 'lanczos', 4., 4., tau=3.)

@@ -557,12 +557,12 @@ def gen_c2():
         hit = bvh.intersect(r, isect)
         r2 = geo.Ray(geo.Point(*rays[i, 0:3]), geo.Vector(*rays[i, 3:6]), rays[i, 6], rays[i, 7])
         res[i] = (int(hit), prim_index[id(isect.primitive)] if hit else -1, r.maxt, int(bvh.intersect_p(r2)))
-    d['rays'] = rays
-    d['res'] = res
+    d['bvh_rays'] = rays
+    d['bvh_res'] = res
     print('c2: %d nodes, %d tris, ray hits %d, %.1fs' % (d['n_nodes'], d['n_tris'], int(res[:, 0].sum()), time.time() - t),
           flush=True)
     # a window of the C2 render itself
-    w = instrumented_render(model, 512, 512, 4, 4, DirectLightingIntegrator(), seed=3, sub=(250, 262, 180, 190))
+    w = instrumented_render(model, 512, 512, 4, 4, DirectLightingIntegrator(), seed=3, sub=(106, 118, 158, 168))
     for k, v in w.items():
         if not k.startswith('log_hitgeo'):
             d[k] = v
