@@ -46,6 +46,10 @@ def parse():
     ap.add_argument('--spp', type=int, default=8, help='strata per axis (spp = spp^2)')
     ap.add_argument('--integrator', choices=['path', 'direct'], default='path')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['head', 'c2', 'c4'], default='head',
+                    help='head = BASELINE.json configs[2] (the metric; default).  Secondary, for DESIGN.md only: '
+                         'c2 = configs[1] head_loop 512^2 x 16 spp Direct; c4 = configs[3] 10^6-triangle soup '
+                         '1920x1080 Path (use --spp 16 for the full 256 spp)')
     return ap.parse_args()
 
 
@@ -92,17 +96,35 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local if world > 1 else 0)
 
-    d = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'head_mesh_scene.npz')))
-    flat = pa.flat_scene_from_npz(d)
+    res, xs = args.res, args.spp
+    kind = A.PT_INTEG_PATH if args.integrator == 'path' else A.PT_INTEG_DIRECT
+    xres = yres = res
+    if args.workload == 'head':
+        d = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'head_mesh_scene.npz')))
+        flat = pa.flat_scene_from_npz(d)
+        cam, film = host.head_mesh_camera_film(res, res)
+        wname = 'head_mesh %dx%d, %d spp stratified, %s max_depth 5, Lanczos(4,4,3) film (BASELINE.json configs[2])'
+    elif args.workload == 'c2':
+        from pytracer_amd import workloads
+        flat = workloads.c2_head_loop(os.path.join(ROOT, 'tests', 'golden', 'c2_head_loop.npz'))
+        xres = yres = res = 512 if args.res == 1024 else args.res
+        xs = 4 if args.spp == 8 else args.spp
+        kind = A.PT_INTEG_DIRECT
+        cam, film = host.head_mesh_camera_film(res, res)
+        wname = 'head_loop (Loop-subdivided head) %dx%d, %d spp, %s, Lanczos(4,4,3) film (BASELINE.json configs[1])'
+    else:
+        from pytracer_amd import workloads
+        flat = workloads.c4_soup()
+        xres, yres = 1920, 1080
+        xs = 4 if args.spp == 8 else args.spp
+        cam, film = workloads.c4_camera_film(xres, yres)
+        wname = '10^6-triangle soup %dx%d, %d spp, %s max_depth 5, spot + sphere lights (BASELINE.json configs[3])'
     ctx = Context(dev.index)
     ctx.upload(flat)
     ctx.set_profiling(True)
-    res, xs = args.res, args.spp
-    cam, film = host.head_mesh_camera_film(res, res)
-    kind = A.PT_INTEG_PATH if args.integrator == 'path' else A.PT_INTEG_DIRECT
     integ = pa.integrator_desc(kind, 5, pretest=False)
-    smp = pa.sampler_desc(0, res, 0, res, xs, xs, True, seed=rank)
-    tile = pa.tile_desc(0, res, 0, res, 0, xs * xs)
+    smp = pa.sampler_desc(0, xres, 0, yres, xs, xs, True, seed=rank)
+    tile = pa.tile_desc(0, xres, 0, yres, 0, xs * xs)
     acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device=dev)
 
     def barrier():
@@ -169,9 +191,7 @@ def main():
             'samples_per_s': samples_total / dt,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'head_mesh %dx%d, %d spp stratified, %s max_depth 5, Lanczos(4,4,3) film '
-                                   '(BASELINE.json configs[2])' % (res, res, xs * xs,
-                                                                    'PathIntegrator' if kind else 'DirectLightingIntegrator'),
+            'config': {'workload': wname % (xres, yres, xs * xs, 'PathIntegrator' if kind else 'DirectLightingIntegrator'),
                        'triangles': flat.n_tris, 'bvh_nodes': flat.n_nodes,
                        'rays_per_sample': rays_total / max(samples_total, 1),
                        'parallelism': 'replicated scene, per-rank sample streams, RCCL film reduce'
@@ -179,7 +199,7 @@ def main():
                        'image_checksum': float(rgb.sum().item())},
             'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'head':
             out['cpu_baseline'] = cpu_baseline(flat, cam, film, integ, res, xs)
         print(json.dumps(out))
     if dist is not None:

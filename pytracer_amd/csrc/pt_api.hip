@@ -30,8 +30,9 @@ struct pt_ctx {
     Queue q[2];
     ShadowQueue sh;
     PathState st;
-    int use_top;             // PT_TRACE_TOP=1: stage the top of the tree in LDS (k_trace_top); measured 5 % slower
-                             // than the plain kernel on the head mesh, so off by default
+    int use_top;             // stage the top of the tree in LDS (k_trace_top): PT_TRACE_TOP=0 never, 1 always,
+                             // unset = for trees beyond the L2 (>= 2^18 nodes = 16 MB).  Measured:
+                             // head mesh 5.5 k nodes -5 %, head_loop 352 k nodes +5 %, 10^6-triangle soup +19 %
     int *hit_idx;            // [cap] hit list of the current closest-hit trace (HitList::idx)
     int *d_counts;           // [4][PT_SEG]: region fill counters of q0, q1, the shadow queue and the hit list
     int trace_occ[2];        // resident blocks/CU of the closest / any trace kernels (0 = not queried)
@@ -98,7 +99,7 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATE_CHK(hipMalloc((void **)&c->d_counts, 4 * PT_CNT_BLOCK * sizeof(int)));
-    c->use_top = 0;
+    c->use_top = -1;
     if (const char *e = getenv("PT_TRACE_TOP")) c->use_top = atoi(e);
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
     CREATE_CHK(hipMalloc((void **)&c->d_counters, PT_CNT_SHARDS * CNT_COUNT * sizeof(unsigned long long)));
@@ -364,7 +365,7 @@ static int trace_grid(pt_ctx *c, long n, bool any) {
 static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t stream, const double *rays, long stride,
                                const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t, double *out_b1,
                                double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
-    if (c->top_stack > 0 && c->use_top) {
+    if (c->top_stack > 0 && (c->use_top > 0 || (c->use_top < 0 && c->sc.n_nodes >= (1 << 18)))) {
         const long blocks = (n_bound + 1023) / 1024;
         const int grid = (int)std::max<long>(1, std::min<long>(blocks, c->n_cu));
         return pt_launch_trace_top(any, c->top_stack, grid, stream, c->sc, rays, stride, seg_counts, seg, n_val, out_prim,

@@ -66,3 +66,29 @@ def c4_camera_film(x_res=1920, y_res=1080):
     ar = float(x_res) / float(y_res)
     cam = host.perspective_camera(host._translate(0., 0., -30.), [-ar, ar, -1., 1.], 60., x_res, y_res)
     return cam, host.image_film(x_res, y_res, 'lanczos', 4., 4., tau=3.)
+
+
+def c2_head_loop(npz_path):
+    """FlatScene of configs[1] (examples/head_loop.py) from the committed fixture: the Loop-subdivided
+    meshes as the reference produced them, tree rebuilt natively (bit-identical to the reference's;
+    tests/test_c2_head_loop.py).  Primitive.full_refine hands over each mesh's triangles in reverse
+    (aggregate/primitive.py:68-75)."""
+    from .flatten import FlatScene, _MAT_KINDS
+    d = dict(np.load(npz_path))
+    tris, mats = [], []
+    for j in range(2):
+        tv = d['mesh%d_p' % j][d['mesh%d_idx' % j]].reshape(-1, 9)[::-1]
+        tris.append(tv)
+        mats.append(np.full(len(tv), int(d['mesh%d_mat' % j]), np.int32))
+    tv, tm = np.concatenate(tris), np.concatenate(mats)
+    nb, nm, order, _ = accel.build_bvh(accel.triangle_bounds(tv))
+    lobes = []
+    for i in range(int(d['n_materials'])):
+        pre = 'mat%d_' % i
+        params = {k[len(pre):]: d[k] for k in d if k.startswith(pre) and k != pre + 'kind'}
+        lobes.append(lobes_from_params(_MAT_KINDS[int(d[pre + 'kind'])], **params))
+    lights = []
+    for i in range(int(d['n_lights'])):
+        pre = 'light%d_' % i
+        lights.append({k[len(pre):]: (d[k].item() if d[k].ndim == 0 else d[k]) for k in d if k.startswith(pre)})
+    return FlatScene(nb, nm, tv[order], tm[order], np.zeros(len(tv), np.int32), lobes, lights)
