@@ -116,6 +116,10 @@ def dump_scene(scene, camera=None):
                              Kr=np.array(mt.Kr(None)), Kt=np.array(mt.Kt(None)),
                              roughness=float(mt.roughness(None)), opacity=np.array(mt.opacity(None)),
                              eta=float(mt.eta(None))))
+        elif nm == 'MirrorMaterial':
+            mrec.append(dict(kind=3, Kr=np.array(mt.Kr(None))))
+        elif nm == 'GlassMaterial':
+            mrec.append(dict(kind=4, Kr=np.array(mt.Kr(None)), Kt=np.array(mt.Kt(None)), index=float(mt.index(None))))
         elif nm == 'PlasticMaterial':
             mrec.append(dict(kind=2, Kd=np.array(mt.Kd(None)), Ks=np.array(mt.Ks(None)),
                              roughness=float(mt.roughness(None))))
@@ -441,10 +445,10 @@ class C4Mini(object):
     front of a matte wall, lit by a SpotLight, a PointLight and a sphere DiffuseAreaLight; camera at
     (0,0,-30) looking +z, fov 60."""
 
-    def __init__(self):
+    def __init__(self, variant='lights'):
         from pytracer.shape import Sphere, create_triangle_mesh
         from pytracer.transform import Transform
-        from pytracer.material import MatteMaterial, PlasticMaterial
+        from pytracer.material import MatteMaterial, PlasticMaterial, MirrorMaterial, GlassMaterial, UberMaterial
         from pytracer.texture import ConstantTexture
         from pytracer.light import SpotLight, PointLight, DiffuseAreaLight
         from pytracer.scene import Scene
@@ -461,14 +465,24 @@ class C4Mini(object):
                 PlasticMaterial(ConstantTexture(Spectrum([.2, .4, .6])), ConstantTexture(Spectrum([.3, .3, .3])),
                                 ConstantTexture(0.05)),
                 MatteMaterial(ConstantTexture(Spectrum([.5, .5, .5])), ConstantTexture(20.))]    # Oren-Nayar wall
-        for k in range(2):
-            P = tri[k::2].reshape(-1, 3)
+        nmesh = 2
+        if variant == 'spec':
+            # specular chains: a mirror, glass, and an Uber material with a specular-reflection component
+            c3 = lambda v: ConstantTexture(Spectrum(v))
+            mats = [MirrorMaterial(c3([.9, .8, .7])),
+                    GlassMaterial(c3([.8, .8, .8]), c3([.7, .9, .7]), ConstantTexture(1.5)),
+                    UberMaterial(c3([.3, .2, .2]), c3([.2, .2, .2]), c3([.5, .5, .5]), c3([0., 0., 0.]),
+                                 ConstantTexture(.2), c3([1., 1., 1.]), ConstantTexture(1.33)),
+                    MatteMaterial(c3([.5, .5, .5]), ConstantTexture(0.))]
+            nmesh = 3
+        for k in range(nmesh):
+            P = tri[k::nmesh].reshape(-1, 3)
             mesh = create_triangle_mesh(ident, ident.inverse(), False,
                                         {'indices': list(range(len(P))), 'P': list(P.ravel())})
             prims.append(GeometricPrimitive(mesh, mats[k]))
             self.in_tris.append(P.reshape(-1, 9))
         wall = {'indices': [0, 1, 2, 2, 0, 3], 'P': [-30, -30, 9, 30, -30, 9, 30, 30, 9, -30, 30, 9]}
-        prims.append(GeometricPrimitive(create_triangle_mesh(ident, ident.inverse(), False, wall), mats[2]))
+        prims.append(GeometricPrimitive(create_triangle_mesh(ident, ident.inverse(), False, wall), mats[nmesh]))
         w = np.array(wall['P'], float).reshape(-1, 3)
         self.in_tris.append(w[np.array(wall['indices'])].reshape(-1, 9))
         # +z of the light frame towards the origin (Transform.look_at mixes up rows and columns, so compose)
@@ -478,6 +492,8 @@ class C4Mini(object):
         lights = [SpotLight(spot_l2w, Spectrum(200.), 30., 25.),
                   PointLight(Transform.translate(geo.Vector(8., -6., -12.)), Spectrum(150.)),
                   DiffuseAreaLight(st, Spectrum(10.), 2, sph)]
+        if variant == 'spec':
+            lights = lights[1:]
         self.scene = Scene(BVH(prims), lights, None)
 
     @staticmethod
@@ -571,7 +587,24 @@ def gen_c2():
                                                                           time.time() - t))
 
 
-ALL = dict(c2=gen_c2, c4mini=gen_c4mini, scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
+def gen_specmini():
+    """Specular chains (Mirror, Glass, Uber with Kr): DirectLightingIntegrator recursing through
+    specular_reflect / specular_transmit (integrator/utility.py:120-200) and PathIntegrator sampling
+    specular lobes."""
+    model = C4Mini('spec')
+    cam = model.configure_camera(x_res=24, y_res=24, file_name='/tmp/_fixture.png')
+    sc = dump_scene(model.scene, cam)
+    for name, integ, xs in (('direct', DirectLightingIntegrator(), 1), ('path', PathIntegrator(max_depth=5), 2)):
+        t = time.time()
+        d = instrumented_render(model, 24, 24, xs, xs, integ, seed=11)
+        d.update(sc)
+        np.savez_compressed(os.path.join(OUT, 'specmini_%s_24x24x%d.npz' % (name, xs * xs)), **d)
+        kinds = d['log_rays'][:, 1].astype(int)
+        print('specmini %s: %.1fs, closest %d any %d (samples %d), sumL %.6f' % (
+            name, time.time() - t, (kinds == 0).sum(), (kinds == 1).sum(), len(d['L']), d['L'].sum()))
+
+
+ALL = dict(specmini=gen_specmini, c2=gen_c2, c4mini=gen_c4mini, scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)
