@@ -106,7 +106,8 @@ def main():
         wname = 'head_mesh %dx%d, %d spp stratified, %s max_depth 5, Lanczos(4,4,3) film (BASELINE.json configs[2])'
     elif args.workload == 'c2':
         from pytracer_amd import workloads
-        flat = workloads.c2_head_loop(os.path.join(ROOT, 'tests', 'golden', 'c2_head_loop.npz'))
+        flat = workloads.c2_head_loop(os.path.join(ROOT, 'tests', 'golden', 'c2_head_loop.npz'),
+                                      os.path.join(ROOT, 'tests', 'golden', 'loop_subdiv.npz'))
         xres = yres = res = 512 if args.res == 1024 else args.res
         xs = 4 if args.spp == 8 else args.spp
         kind = A.PT_INTEG_DIRECT

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 typedef enum {
     PT_OK = 0,
@@ -223,6 +223,26 @@ int pt_bvh_build(const double *prim_bounds, int64_t n, int32_t max_prim_per_node
                  double *node_bounds, int32_t *node_meta, int32_t *prim_order, int64_t *n_nodes,
                  int32_t *max_depth);
 const char *pt_build_last_error(void);
+
+/* replaces: LoopSubdiv.__init__ + LoopSubdiv.refine (shape/loopsubdiv.py:195-247,293-446, created by
+ * create_loop_subdiv :19-44).  Host-side, needs no GPU and no context.  Same vertex and face order
+ * and the same floating-point summation order as the reference, so the result equals its
+ * TriangleMesh bit for bit (vertex normals, which never reach shading — triangle.py:325 — are not
+ * produced).
+ *   P         host f64 [nv][3] object-space control vertices, vi host i32 [nf][3]
+ *   n_levels  create_loop_subdiv's 'nlevels' (default 3 there)
+ *   P_out     host f64 [p_cap][3] limit-surface vertices (object space; the caller applies o2w like
+ *             create_triangle_mesh, triangle.py:426-435), idx_out host i32 [idx_cap]
+ *   nv_out/nf_out  vertices / triangles produced (nf * 4^n_levels triangles, at most
+ *             nv + nf * (4^n_levels - 1) vertices); PT_ERR_CAPACITY if the buffers are smaller
+ * Returns PT_ERR_ARG where the reference itself fails: inconsistent topology (its RuntimeError in
+ * vnum), unused vertices, and any mesh whose vertex 0 is interior — refine() raises
+ * UnboundLocalError in its tangent pass then (:409), which includes every closed mesh.
+ * pt_subdiv_last_error() has the text (thread-local). */
+int pt_loop_subdiv(const double *P, int64_t nv, const int32_t *vi, int64_t nf, int32_t n_levels,
+                   double *P_out, int64_t p_cap, int32_t *idx_out, int64_t idx_cap,
+                   int64_t *nv_out, int64_t *nf_out);
+const char *pt_subdiv_last_error(void);
 
 #ifdef __cplusplus
 }

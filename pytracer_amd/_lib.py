@@ -13,7 +13,8 @@ if os.environ.get('PYTRACER_HIP_LIB'):        # kernel A/B experiments only (scr
     LIB_PATH = os.path.abspath(os.environ['PYTRACER_HIP_LIB'])
 
 EXPORTS = ('pt_version', 'pt_ctx_create', 'pt_ctx_destroy', 'pt_last_error', 'pt_scene_upload', 'pt_intersect',
-           'pt_render', 'pt_film_resolve', 'pt_set_profiling', 'pt_bvh_build', 'pt_build_last_error')
+           'pt_render', 'pt_film_resolve', 'pt_set_profiling', 'pt_bvh_build', 'pt_build_last_error',
+           'pt_loop_subdiv', 'pt_subdiv_last_error')
 
 _lib = None
 
@@ -52,6 +53,9 @@ def lib():
         L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.pt_build_last_error.restype = C.c_char_p
+        L.pt_loop_subdiv.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.pt_subdiv_last_error.restype = C.c_char_p
         if L.pt_version() != A.PT_ABI_VERSION:
             raise ImportError('libpytracer_hip.so ABI %d != expected %d' % (L.pt_version(), A.PT_ABI_VERSION))
         _lib = L

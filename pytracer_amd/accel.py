@@ -56,6 +56,44 @@ def build_bvh(prim_bounds, max_prim_per_node=4, method='sah'):
     return nb[:k].copy(), nm[:k].copy(), order[:n].copy(), depth.value
 
 
+def loop_subdivide(P, indices, n_levels=3):
+    """LoopSubdiv.refine (shape/loopsubdiv.py:293-446) natively: control mesh (P [nv,3] object space,
+    indices [nf*3]) → (limit-surface vertices [nv',3], indices [nf * 4^n_levels * 3]), bit-identical to
+    the reference's TriangleMesh before its object-to-world transform.  Raises ValueError where the
+    reference itself raises (e.g. closed meshes: UnboundLocalError in its tangent pass)."""
+    from ._lib import lib
+    P = np.ascontiguousarray(P, np.float64).reshape(-1, 3)
+    vi = np.ascontiguousarray(indices, np.int32).ravel()
+    if len(vi) % 3:
+        raise ValueError('indices must hold whole triangles')
+    nv, nf = len(P), len(vi) // 3
+    nf_out = nf * 4 ** int(n_levels)
+    nv_cap = nv + nf * (4 ** int(n_levels) - 1)
+    Po = np.empty((max(nv_cap, 1), 3), np.float64)
+    io = np.empty(max(3 * nf_out, 1), np.int32)
+    a, b = C.c_int64(0), C.c_int64(0)
+    L = lib()
+    rc = L.pt_loop_subdiv(P.ctypes.data, nv, vi.ctypes.data, nf, int(n_levels), Po.ctypes.data, len(Po),
+                          io.ctypes.data, len(io), C.byref(a), C.byref(b))
+    if rc != 0:
+        raise ValueError('pt_loop_subdiv: %s' % L.pt_subdiv_last_error().decode('utf-8', 'replace'))
+    return Po[:a.value].copy(), io[:3 * b.value].copy()
+
+
+def create_loop_subdiv(o2w, w2o, ro, params):
+    """Drop-in for pytracer.shape.create_loop_subdiv (shape/loopsubdiv.py:19-44) in a scene script that
+    has the reference importable: subdivides natively and returns the refined reference ``TriangleMesh``
+    (what ``LoopSubdiv.refine()`` would hand to the aggregate, loopsubdiv.py:441-446) — same vertices,
+    same indices, without the minutes of Python object juggling."""
+    from pytracer.shape import create_triangle_mesh        # the reference's own mesh class
+    nlevels = params.get('nlevels', 3)
+    vi, P = params.get('indices'), params.get('P')
+    if vi is None or P is None or len(P) % 3 or len(vi) % 3:
+        return None                                        # loopsubdiv.py:25-34
+    Po, io = loop_subdivide(np.asarray(P, np.float64).reshape(-1, 3), vi, nlevels)
+    return create_triangle_mesh(o2w, w2o, ro, {'indices': [int(k) for k in io], 'P': [float(x) for x in Po.ravel()]})
+
+
 def flat_scene_from_triangles(tri_verts, material_lobes, light_records=(), tri_mat=None, tri_flip=None,
                               max_prim_per_node=4, method='sah'):
     """FlatScene from a world-space triangle list in primitive order (what a reference script hands

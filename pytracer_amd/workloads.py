@@ -68,18 +68,24 @@ def c4_camera_film(x_res=1920, y_res=1080):
     return cam, host.image_film(x_res, y_res, 'lanczos', 4., 4., tau=3.)
 
 
-def c2_head_loop(npz_path):
-    """FlatScene of configs[1] (examples/head_loop.py) from the committed fixture: the Loop-subdivided
-    meshes as the reference produced them, tree rebuilt natively (bit-identical to the reference's;
-    tests/test_c2_head_loop.py).  Primitive.full_refine hands over each mesh's triangles in reverse
-    (aggregate/primitive.py:68-75)."""
+def c2_meshes(c2_npz, loop_npz):
+    """World-space meshes [(P, idx, material)] of examples/head_loop.py: the head = 3 levels of Loop
+    subdivision of the control mesh (examples/head_model.py data, held by loop_subdiv.npz), translated
+    like create_triangle_mesh does (head_loop.py:59-60); the backdrop from the C2 fixture."""
+    d, base = np.load(c2_npz), np.load(loop_npz)
+    P, idx = accel.loop_subdivide(base['head_P'], base['head_idx'], 3)
+    return [(P + d['mesh0_o2w_translate'], idx, int(d['mesh0_mat'])),
+            (d['mesh1_p'], d['mesh1_idx'], int(d['mesh1_mat']))], dict(d)
+
+
+def c2_head_loop(c2_npz, loop_npz):
+    """FlatScene of configs[1] (examples/head_loop.py), built natively end to end: Loop subdivision,
+    then the reference-exact BVH (both bit-identical to the reference's; tests/test_c2_head_loop.py).
+    Primitive.full_refine hands over each mesh's triangles in reverse (aggregate/primitive.py:68-75)."""
     from .flatten import FlatScene, _MAT_KINDS
-    d = dict(np.load(npz_path))
-    tris, mats = [], []
-    for j in range(2):
-        tv = d['mesh%d_p' % j][d['mesh%d_idx' % j]].reshape(-1, 9)[::-1]
-        tris.append(tv)
-        mats.append(np.full(len(tv), int(d['mesh%d_mat' % j]), np.int32))
+    meshes, d = c2_meshes(c2_npz, loop_npz)
+    tris = [P[idx].reshape(-1, 9)[::-1] for P, idx, _ in meshes]
+    mats = [np.full(len(t), m, np.int32) for t, (_, _, m) in zip(tris, meshes)]
     tv, tm = np.concatenate(tris), np.concatenate(mats)
     nb, nm, order, _ = accel.build_bvh(accel.triangle_bounds(tv))
     lobes = []

@@ -2,9 +2,9 @@
 (177 666 triangles, 352 417 BVH nodes), DirectLightingIntegrator, 512x512, 4x4 spp.
 
 tests/golden/c2_head_loop.npz was written by running the reference (tools/oracle/gen_fixtures.py:gen_c2):
-the subdivided meshes, SHA-256 digests of the reference's flattened tree (too big to commit), 300
+SHA-256 digests of the subdivided head mesh and of the reference's flattened tree (too big to commit), 300
 reference-traced rays and the reference's render of a 12x10-pixel window across the head's silhouette.
-CPU part: the native builder reproduces the tree bit for bit; oracle vs reference.  GPU part: the HIP
+CPU part: native Loop subdivision of the control mesh and the native builder reproduce mesh and tree bit for bit; oracle vs reference.  GPU part: the HIP
 path on that tree vs reference and oracle, and the whole C2 render through size-independent
 properties."""
 import hashlib
@@ -36,30 +36,25 @@ def rays_from_log(log):
 
 @pytest.fixture(scope='module')
 def c2(golden_dir):
-    d = dict(np.load(os.path.join(golden_dir, 'c2_head_loop.npz')))
-    # BVH([head, back]): Primitive.full_refine hands over each mesh's triangles in reverse (primitive.py:68-75)
-    tris, mats = [], []
-    for j in range(2):
-        tv = d['mesh%d_p' % j][d['mesh%d_idx' % j]].reshape(-1, 9)[::-1]
-        tris.append(tv)
-        mats.append(np.full(len(tv), int(d['mesh%d_mat' % j]), np.int32))
-    tv, tm = np.concatenate(tris), np.concatenate(mats)
-    nb, nm, order, depth = accel.build_bvh(accel.triangle_bounds(tv))
-    lobes = []
-    for i in range(int(d['n_materials'])):
-        pre = 'mat%d_' % i
-        params = {k[len(pre):]: d[k] for k in d if k.startswith(pre) and k != pre + 'kind'}
-        lobes.append(lobes_from_params(_MAT_KINDS[int(d[pre + 'kind'])], **params))
-    lights = []
-    for i in range(int(d['n_lights'])):
-        pre = 'light%d_' % i
-        lights.append({k[len(pre):]: (d[k].item() if d[k].ndim == 0 else d[k]) for k in d if k.startswith(pre)})
-    flat = FlatScene(nb, nm, tv[order], tm[order], np.zeros(len(tv), np.int32), lobes, lights)
-    return d, flat, depth
+    from pytracer_amd import workloads
+    c2_npz, loop_npz = os.path.join(golden_dir, 'c2_head_loop.npz'), os.path.join(golden_dir, 'loop_subdiv.npz')
+    d = dict(np.load(c2_npz))
+    flat = workloads.c2_head_loop(c2_npz, loop_npz)       # native Loop subdivision + native BVH build
+    meshes, _ = workloads.c2_meshes(c2_npz, loop_npz)
+    d['_mesh0'] = meshes[0]
+    return d, flat, None
 
 
 def digest(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def test_native_subdivision_reproduces_the_reference_mesh(c2):
+    d, _, _ = c2
+    P, idx, _ = d['_mesh0']
+    assert len(P) == int(d['mesh0_nverts']) == 89078 and len(idx) == 3 * int(d['mesh0_ntris'])
+    assert np.array_equal(digest(P), d['sha256_mesh0_p'])
+    assert np.array_equal(digest(idx.astype(np.int32)), d['sha256_mesh0_idx'])
 
 
 def test_native_builder_reproduces_the_reference_tree(c2):
@@ -70,7 +65,6 @@ def test_native_builder_reproduces_the_reference_tree(c2):
     assert np.array_equal(digest(flat.tri_verts), d['sha256_tri_verts'])      # = the reference's primitive order
     assert np.array_equal(digest(flat.tri_mat), d['sha256_tri_mat'])
     assert np.array_equal(digest(flat.tri_flip), d['sha256_tri_flip'])
-    assert 24 < depth <= 64
 
 
 def test_oracle_on_reference_rays_and_window(c2):

@@ -528,8 +528,8 @@ def gen_c4mini():
 def gen_c2():
     """C2 (BASELINE.json configs[1]): examples/head_loop.py — the head mesh after 3 levels of Loop
     subdivision (177 666 triangles), 512x512, 4x4 spp, DirectLightingIntegrator.  Importing the example
-    runs the reference's subdivision and its Python BVH build (minutes).  The fixture holds the
-    subdivided mesh (the builder's INPUT), digests of the reference's tree (352 k nodes are too big to
+    runs the reference's subdivision and its Python BVH build (minutes).  The fixture holds
+    digests of the subdivided mesh (the builder's INPUT), the backdrop mesh, digests of the reference's tree (352 k nodes are too big to
     commit), reference-traced rays, and a reference render of a small window."""
     import hashlib
     t = time.time()
@@ -553,8 +553,19 @@ def gen_c2():
     order = sorted(range(len(meshes)), key=lambda i: -meshes[i].ntris)      # head first, backdrop second
     for j, i in enumerate(order):
         m = meshes[i]
-        d['mesh%d_p' % j] = np.array([np.array(p) for p in m.p], np.float64)
-        d['mesh%d_idx' % j] = np.array(m.vertexIndex, np.int32)
+        mp = np.array([np.array(p) for p in m.p], np.float64)
+        mi = np.array(m.vertexIndex, np.int32)
+        if j == 0:
+            # the subdivided head (89 078 vertices): digests only — pt_loop_subdiv reproduces it bit for
+            # bit from the control mesh in loop_subdiv.npz (tests/test_loop_subdiv_cpu.py)
+            d['sha256_mesh0_p'] = np.frombuffer(hashlib.sha256(mp.tobytes()).digest(), np.uint8)
+            d['sha256_mesh0_idx'] = np.frombuffer(hashlib.sha256(mi.tobytes()).digest(), np.uint8)
+            d['mesh0_nverts'] = np.int64(len(mp))
+            d['mesh0_ntris'] = np.int64(len(mi) // 3)
+            d['mesh0_o2w_translate'] = np.array([-3., 6., -15.])      # examples/head_loop.py:59
+        else:
+            d['mesh%d_p' % j] = mp
+            d['mesh%d_idx' % j] = mi
         d['mesh%d_mat' % j] = np.int32(sc['tri_mat'][[k for k, pr in enumerate(bvh.primitives) if pr.shape.mesh is m][0]])
     # reference-traced rays
     rng = np.random.default_rng(2024)
@@ -604,7 +615,56 @@ def gen_specmini():
             name, time.time() - t, (kinds == 0).sum(), (kinds == 1).sum(), len(d['L']), d['L'].sum()))
 
 
-ALL = dict(specmini=gen_specmini, c2=gen_c2, c4mini=gen_c4mini, scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
+def gen_loop():
+    """F9: LoopSubdiv.refine (shape/loopsubdiv.py:293-446) on small meshes — a closed octahedron
+    (valence-4 extraordinary vertices), an open 4x3 grid (boundary rules) and a closed mesh with
+    valence-3 and valence-5 vertices — at 1..3 levels; plus the base head mesh of
+    examples/head_model.py (data), whose 3-level result is the mesh held by c2_head_loop.npz."""
+    from pytracer.shape import create_loop_subdiv
+    from pytracer.transform import Transform
+    ident = Transform.translate(geo.Vector(0., 0., 0.))
+    cases = {}
+    cases['octa'] = (np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], float) * 1.3,
+                     [0, 2, 4, 2, 1, 4, 1, 3, 4, 3, 0, 4, 2, 0, 5, 1, 2, 5, 3, 1, 5])    # face (0,3,5) left out, below
+    gx, gy = 4, 3
+    rng = np.random.default_rng(3)
+    P = np.array([[x, y, .3 * rng.normal()] for y in range(gy) for x in range(gx)], float)
+    idx = []
+    for y in range(gy - 1):
+        for x in range(gx - 1):
+            a = y * gx + x
+            idx += [a, a + 1, a + gx, a + 1, a + gx + 1, a + gx]
+    cases['grid'] = (P, idx)
+    # tetrahedron with one face split into three: valences 3, 3, 4, 4... and a 5-valent apex via a pentagonal bipyramid
+    n = 5
+    ring = [[np.cos(2 * np.pi * k / n), np.sin(2 * np.pi * k / n), 0.1 * k] for k in range(n)]
+    P = np.array(ring + [[0, 0, 1.2], [0, 0, -.9]], float)
+    idx = []
+    for k in range(n):
+        idx += [k, (k + 1) % n, n, (k + 1) % n, k, n + 1]
+    cases['bipyramid'] = (P, idx[3:])          # first face left out
+    # NB: every mesh is OPEN at vertex 0.  The tangent pass of refine() does `S += ...` for interior
+    # vertices before S exists (loopsubdiv.py:409): a mesh whose first vertex is interior raises
+    # UnboundLocalError in the reference, so closed meshes cannot be subdivided by it at all.
+    d = {}
+    for name, (P, idx) in cases.items():
+        d[name + '_P'] = np.asarray(P, np.float64)
+        d[name + '_idx'] = np.asarray(idx, np.int32)
+        for lv in (1, 2, 3):
+            sd = create_loop_subdiv(ident, ident.inverse(), False,
+                                    {'indices': list(idx), 'P': list(np.asarray(P, float).ravel()), 'nlevels': lv})
+            m = sd.refine()[0]
+            d['%s_l%d_P' % (name, lv)] = np.array([np.array(q) for q in m.p], np.float64)
+            d['%s_l%d_idx' % (name, lv)] = np.array(m.vertexIndex, np.int32)
+            print('loop %s level %d: %d verts %d tris' % (name, lv, len(m.p), m.ntris))
+    from examples.head_model import model as head_model
+    d['head_P'] = np.array(head_model['P'], np.float64).reshape(-1, 3)
+    d['head_idx'] = np.array(head_model['indices'], np.int32)
+    np.savez_compressed(os.path.join(OUT, 'loop_subdiv.npz'), **d)
+    print('loop: head base %d verts %d tris' % (len(d['head_P']), len(d['head_idx']) // 3))
+
+
+ALL = dict(loop=gen_loop, specmini=gen_specmini, c2=gen_c2, c4mini=gen_c4mini, scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)
