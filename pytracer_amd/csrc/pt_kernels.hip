@@ -805,6 +805,7 @@ hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene 
 // once with global f64 atomics: ~0.7 global atomics per sample instead of 324.
 // =========================================================================================
 #define SPLAT_PX 32
+#define SPLAT_GROUP 8
 
 __device__ __forceinline__ d3 guarded_radiance(d3 L, unsigned long long *counters) {
     if (isnan(L.x) || isnan(L.y) || isnan(L.z)) {
@@ -847,48 +848,107 @@ __global__ __launch_bounds__(PT_BLOCK) void k_splat(const RenderConst *__restric
     const long P = st.stride;
     const double xwInv = 1. / fm.xw, ywInv = 1. / fm.yw;
     const int fx1 = fm.x_start + fm.x_cnt - 1, fy1 = fm.y_start + fm.y_cnt - 1;
+    // taps of ONE sample, each added on its own (the general path)
+    auto splat_taps = [&](double dX, double dY, int x0, int x1, int y0, int y1, double X, double Y, double Z) {
+        const bool in_tile = use_lds && x0 >= lx0 && x1 < lx0 + tw_l && y0 >= ly0 && y1 < ly0 + th_l;
+        for (int y = y0; y <= y1; y++) {
+            int ify = (int)floor(fabs((y - dY) * 16 * ywInv));
+            ify = min(ify, 15);
+            for (int x = x0; x <= x1; x++) {
+                int ifx = (int)floor(fabs((x - dX) * 16 * xwInv));
+                ifx = min(ifx, 15);
+                const double wt = fm.table[ify * 16 + ifx];
+                double *t = in_tile ? s_tile + (y - ly0) * tw_l + (x - lx0)
+                                    : film + 4 * ((size_t)(y - fm.y_start) * fm.x_cnt + (x - fm.x_start));
+                const int cs = in_tile ? plane : 1;
+                unsafeAtomicAdd(t, wt * X);
+                unsafeAtomicAdd(t + cs, wt * Y);
+                unsafeAtomicAdd(t + 2 * cs, wt * Z);
+                unsafeAtomicAdd(t + 3 * cs, wt);
+            }
+        }
+    };
     if (px_t < tw) {
         const long pix_i = ((long)row * tw + px_t) * ns;
-        for (int s = sub; s < ns; s += PT_BLOCK / SPLAT_PX) {
-            const long out_i = pix_i + s;
-            if (out_i < base || out_i >= base + nb) continue;
-            const int slot = (int)(out_i - base);
-            d3 L = guarded_radiance(mk3(st.L[slot], st.L[P + slot], st.L[2 * P + slot]), counters);
-            if (sample_L) {
-                sample_L[3 * out_i] = L.x; sample_L[3 * out_i + 1] = L.y; sample_L[3 * out_i + 2] = L.z;
+        constexpr int STEP = PT_BLOCK / SPLAT_PX;
+        // Every sample of this pixel has imageX in [px, px+1), so all their footprints fall in one
+        // window of <= 2w+2 pixels per axis.  A thread gathers SPLAT_GROUP of its samples and adds their
+        // SUM to each window pixel: 4 LDS atomics per window pixel instead of 4 per sample tap (8x fewer
+        // at 64 spp; the LDS atomic rate, not the arithmetic, bounded this kernel).  Per sample and axis
+        // the filter-table index of every window column/row is packed 5 bits apiece (31 = not covered).
+        const int px = rc.tile.x0 + px_t;
+        const int wx0 = (int)ceil(px - .5 - fm.xw), wx1 = (int)floor(px + .5 + fm.xw);
+        const int wy0 = (int)ceil(py - .5 - fm.yw), wy1 = (int)floor(py + .5 + fm.yw);
+        const int W = wx1 - wx0 + 1, H = wy1 - wy0 + 1;
+        const bool grouped = use_lds && film && W <= 12 && H <= 12 && wx0 >= lx0 && wx1 < lx0 + tw_l && wy0 >= ly0 &&
+                             wy1 < ly0 + th_l;
+        for (int s0 = sub; s0 < ns; s0 += STEP * SPLAT_GROUP) {
+            double X[SPLAT_GROUP], Y[SPLAT_GROUP], Z[SPLAT_GROUP];
+            unsigned long long cx[SPLAT_GROUP], cy[SPLAT_GROUP];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < SPLAT_GROUP; j++) {
+                X[j] = Y[j] = Z[j] = 0.;
+                cx[j] = cy[j] = ~0ull;
+                const int sidx = s0 + j * STEP;
+                const long out_i = pix_i + sidx;
+                if (sidx >= ns || out_i < base || out_i >= base + nb) continue;
+                const int slot = (int)(out_i - base);
+                d3 L = guarded_radiance(mk3(st.L[slot], st.L[P + slot], st.L[2 * P + slot]), counters);
+                if (sample_L) {
+                    sample_L[3 * out_i] = L.x; sample_L[3 * out_i + 1] = L.y; sample_L[3 * out_i + 2] = L.z;
+                }
+                if (!film) continue;
+                const double dX = st.img[slot] - .5, dY = st.img[P + slot] - .5;
+                int x0 = (int)ceil(dX - fm.xw), x1 = (int)floor(dX + fm.xw);
+                int y0 = (int)ceil(dY - fm.yw), y1 = (int)floor(dY + fm.yw);
+                x0 = max(x0, fm.x_start); x1 = min(x1, fx1);
+                y0 = max(y0, fm.y_start); y1 = min(y1, fy1);
+                if (x1 - x0 < 0 || y1 - y0 < 0) continue;
+                // rgb2xyz, spectral/spectrum.py:31-34
+                const double Xs = (0.412453 * L.x + 0.357580 * L.y) + 0.180423 * L.z;
+                const double Ys = (0.212671 * L.x + 0.715160 * L.y) + 0.072169 * L.z;
+                const double Zs = (0.019334 * L.x + 0.119193 * L.y) + 0.950227 * L.z;
+                if (!grouped || x0 < wx0 || x1 > wx1 || y0 < wy0 || y1 > wy1) {   // e.g. a host sampler's stray sample
+                    splat_taps(dX, dY, x0, x1, y0, y1, Xs, Ys, Zs);
+                    continue;
+                }
+                X[j] = Xs; Y[j] = Ys; Z[j] = Zs;
+                unsigned long long bx = 0, by = 0;
+                for (int w = 0; w < W; w++) {
+                    const int x = wx0 + w;
+                    int c = 31;
+                    if (x >= x0 && x <= x1) c = min((int)floor(fabs((x - dX) * 16 * xwInv)), 15);
+                    bx |= (unsigned long long)c << (5 * w);
+                }
+                for (int h = 0; h < H; h++) {
+                    const int y = wy0 + h;
+                    int c = 31;
+                    if (y >= y0 && y <= y1) c = min((int)floor(fabs((y - dY) * 16 * ywInv)), 15);
+                    by |= (unsigned long long)c << (5 * h);
+                }
+                cx[j] = bx; cy[j] = by;
+                any = true;
             }
-            if (!film) continue;
-            const double dX = st.img[slot] - .5, dY = st.img[P + slot] - .5;
-            int x0 = (int)ceil(dX - fm.xw), x1 = (int)floor(dX + fm.xw);
-            int y0 = (int)ceil(dY - fm.yw), y1 = (int)floor(dY + fm.yw);
-            x0 = max(x0, fm.x_start); x1 = min(x1, fx1);
-            y0 = max(y0, fm.y_start); y1 = min(y1, fy1);
-            if (x1 - x0 < 0 || y1 - y0 < 0) continue;
-            // rgb2xyz, spectral/spectrum.py:31-34
-            const double X = (0.412453 * L.x + 0.357580 * L.y) + 0.180423 * L.z;
-            const double Y = (0.212671 * L.x + 0.715160 * L.y) + 0.072169 * L.z;
-            const double Z = (0.019334 * L.x + 0.119193 * L.y) + 0.950227 * L.z;
-            const bool in_tile = use_lds && x0 >= lx0 && x1 < lx0 + tw_l && y0 >= ly0 && y1 < ly0 + th_l;
-            for (int y = y0; y <= y1; y++) {
-                int ify = (int)floor(fabs((y - dY) * 16 * ywInv));
-                ify = min(ify, 15);
-                for (int x = x0; x <= x1; x++) {
-                    int ifx = (int)floor(fabs((x - dX) * 16 * xwInv));
-                    ifx = min(ifx, 15);
-                    const double wt = fm.table[ify * 16 + ifx];
-                    if (in_tile) {
-                        double *t = s_tile + (y - ly0) * tw_l + (x - lx0);
-                        unsafeAtomicAdd(t, wt * X);
-                        unsafeAtomicAdd(t + plane, wt * Y);
-                        unsafeAtomicAdd(t + 2 * plane, wt * Z);
-                        unsafeAtomicAdd(t + 3 * plane, wt);
-                    } else {
-                        double *g = film + 4 * ((size_t)(y - fm.y_start) * fm.x_cnt + (x - fm.x_start));
-                        unsafeAtomicAdd(g + 0, wt * X);
-                        unsafeAtomicAdd(g + 1, wt * Y);
-                        unsafeAtomicAdd(g + 2, wt * Z);
-                        unsafeAtomicAdd(g + 3, wt);
+            if (!any) continue;
+            for (int h = 0; h < H; h++) {
+                double *trow = s_tile + (wy0 + h - ly0) * tw_l + (wx0 - lx0);
+                for (int w = 0; w < W; w++) {
+                    double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+                    bool hitp = false;
+#pragma unroll
+                    for (int j = 0; j < SPLAT_GROUP; j++) {
+                        const int ify = (int)(cy[j] >> (5 * h)) & 31, ifx = (int)(cx[j] >> (5 * w)) & 31;
+                        if ((ify | ifx) & 16) continue;
+                        const double wt = fm.table[ify * 16 + ifx];
+                        a0 += wt * X[j]; a1 += wt * Y[j]; a2 += wt * Z[j]; a3 += wt;
+                        hitp = true;
                     }
+                    if (!hitp) continue;
+                    unsafeAtomicAdd(trow + w, a0);
+                    unsafeAtomicAdd(trow + w + plane, a1);
+                    unsafeAtomicAdd(trow + w + 2 * plane, a2);
+                    unsafeAtomicAdd(trow + w + 3 * plane, a3);
                 }
             }
         }
