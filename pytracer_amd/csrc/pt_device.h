@@ -259,8 +259,9 @@ __device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, doubl
         // (montecarlo/utility.py:171-184 on top of uniform_sample_sphere :83-95; Q6)
         double z = 1. - 2. * u1;
         double r = sqrt(max0(1. - z * z));
-        double phi = 2. * PT_PI * u2;
-        d3 wi = mk3(r * cos(phi), r * sin(phi), z);
+        double phi = 2. * PT_PI * u2, sphi, cphi;
+        sincos(phi, &sphi, &cphi);
+        d3 wi = mk3(r * cphi, r * sphi, z);
         wi.z = sqrt(max0(1. - wi.x * wi.x - wi.y * wi.y));
         if (wo.z < 0.) wi.z *= -1.;
         wi_out = wi;
@@ -271,8 +272,9 @@ __device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, doubl
         double e = l.c;
         double ct = pow(u1, 1. / (e + 1));
         double st = sqrt(max0(1. - ct * ct));
-        double phi = u2 * 2. * PT_PI;
-        d3 wh = mk3(st * cos(phi), st * sin(phi), ct);
+        double phi = u2 * 2. * PT_PI, sphi, cphi;
+        sincos(phi, &sphi, &cphi);
+        d3 wh = mk3(st * cphi, st * sphi, ct);
         if (wo.z * wh.z <= 0.) wh = wh * -1.;
         double dwh = dot3(wo, wh);
         d3 wi = (-wo) + (wh * (2. * dwh));
@@ -328,6 +330,44 @@ __device__ inline double bsdf_pdf(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned f
     for (int i = 0; i < vx.mat->n_lobes; i++)
         if (match_flag(vx.mat->lobes[i].type, flags)) { n_match++; pdf += lobe_pdf(vx.mat->lobes[i], wo, wi); }
     return n_match > 0 ? pdf / n_match : 0.;
+}
+
+// BSDF.f and BSDF.pdf for the same pair of directions (estimate_direct evaluates both,
+// integrator/utility.py:221-231).  Same values as bsdf_f / bsdf_pdf; a Blinn microfacet lobe computes
+// its half vector and |cos θh|^e once for both (pow is the most expensive call of the vertex).
+__device__ inline d3 bsdf_f_pdf(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned flags, double &pdf_out) {
+    d3 wi = w2l(vx, wi_w), wo = w2l(vx, wo_w);
+    unsigned fflags = flags;
+    if (dot3(wi_w, vx.nn) * dot3(wo_w, vx.nn) > 0.) fflags &= ~BDF_TRANSMISSION;
+    else fflags &= ~BDF_REFLECTION;
+    d3 f = mk3(0, 0, 0);
+    double pdf = 0.;
+    int n_match = 0;
+    for (int i = 0; i < vx.mat->n_lobes; i++) {
+        const pt_lobe &l = vx.mat->lobes[i];
+        const bool mf = match_flag(l.type, fflags), mp = match_flag(l.type, flags);
+        if (l.type == PT_LOBE_MICROFACET_BLINN && mf && mp && wi.z != 0. && wo.z != 0. && wi.z * wo.z > 0.) {
+            // lobe_f and blinn_pdf share wh = normalize(wo + wi) (addition commutes) and pow(|wh.z|, e)
+            d3 R = mk3(l.R[0], l.R[1], l.R[2]);
+            d3 wh = normalize3(wi + wo);
+            double ct_h = dot3(wi, wh);
+            double F = fresnel_dielectric(ct_h, l.a, l.b);
+            double awh = fabs(wh.z), dwh = dot3(wo, wh), adot = fabs(dwh);
+            double g1 = 2. * awh * fabs(wo.z) / adot, g2 = 2. * awh * fabs(wi.z) / adot;
+            double gm = (g2 < g1) ? g2 : g1;
+            double G = (gm < 1.) ? gm : 1.;
+            double pw = pow(awh, l.c);
+            double D = (l.c + 2) * PT_INV_2PI * pw;
+            f = f + (((R * D) * G) * F) / (4. * wi.z * wo.z);
+            n_match++;
+            if (dwh > 0.) pdf += ((l.c + 1.) * pw) / (2. * PT_PI * 4. * dwh);
+            continue;
+        }
+        if (mf) f = f + lobe_f(l, wo, wi);
+        if (mp) { n_match++; pdf += lobe_pdf(l, wo, wi); }
+    }
+    pdf_out = n_match > 0 ? pdf / n_match : 0.;
+    return f;
 }
 
 // BSDF.sample_f AS IT EXECUTES, bsdf.py:100-154: `bdf.type & SPECULAR` is an object, always
@@ -468,8 +508,9 @@ __device__ inline void sphere_light_sample_l(const pt_light &lt, d3 p, double pE
         // uniform_sample_cone with a basis, montecarlo/utility.py:222-226
         double ct = (1. - u1) * ct_max + u1 * 1.;
         double st = sqrt(1. - ct * ct);
-        double phi = u2 * 2. * PT_PI;
-        d3 dir = ((wcx * (cos(phi) * st)) + (wcy * (sin(phi) * st))) + (wc * ct);
+        double phi = u2 * 2. * PT_PI, sphi, cphi;
+        sincos(phi, &sphi, &cphi);
+        d3 dir = ((wcx * (cphi * st)) + (wcy * (sphi * st))) + (wc * ct);
         Ray r;
         r.o = p; r.d = dir; r.mint = PT_EPS; r.maxt = __builtin_inf();
         double thit;

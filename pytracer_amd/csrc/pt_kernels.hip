@@ -564,13 +564,13 @@ __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, con
     if (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) sphere_light_sample_l(lt, vx.p, vx.rEps, u0, u1, ls);
     else delta_light_sample_l(lt, vx.p, vx.rEps, ls);
     if (!(ls.pdf > 0. && !util_is_black(ls.Li))) return false;
-    d3 f = bsdf_f(vx, wo, ls.wi, flags);
+    double bp = 0.;
+    d3 f = (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) ? bsdf_f_pdf(vx, wo, ls.wi, flags, bp) : bsdf_f(vx, wo, ls.wi, flags);
     if (util_is_black(f)) return false;
     double adot = fabs(dot3(ls.wi, vx.nn));
     if (lt.kind != PT_LIGHT_DIFFUSE_SPHERE) {
         c = (f * ls.Li) * (adot / ls.pdf);
     } else {
-        double bp = bsdf_pdf(vx, wo, ls.wi, flags);
         double ff = 1 * ls.pdf, g = 1 * bp;
         double weight = ff * ff / (ff * ff + g * g);   // power_heuristic, montecarlo/utility.py:33-42
         c = (f * ls.Li) * (adot * weight / ls.pdf);
