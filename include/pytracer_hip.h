@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5
 
 typedef enum {
     PT_OK = 0,
@@ -46,7 +46,10 @@ typedef enum {
                                      FresnelDielectric(a=eta_i, b=eta_t); c = exponent      */
     PT_LOBE_SPEC_REFLECT = 3,     /* bdf.py:229-256; R; FresnelDielectric(a,b); c!=0 →
                                      FresnelFullReflect (fresnel.py:75-83)                  */
-    PT_LOBE_SPEC_TRANSMIT = 4     /* bdf.py:259-307; R=T, a=ei, b=et                        */
+    PT_LOBE_SPEC_TRANSMIT = 4,    /* bdf.py:259-307; R=T, a=ei, b=et                        */
+    PT_LOBE_MICROFACET_BLINN_COND = 5 /* the same Microfacet/Blinn with FresnelConductor(eta[3],
+                                     k[3]) (fresnel.py:30-41, reflection/utility.py:60-73):
+                                     MetalMaterial, material.py:242-258; c = exponent        */
 } pt_lobe_type;
 
 #define PT_MAX_LOBES 5
@@ -56,6 +59,7 @@ typedef struct {
     int32_t _pad;
     double R[3];        /* RGB scale (Spectrum = RGBSpectrum, spectral/spectrum.py:610) */
     double a, b, c;
+    double eta[3], k[3];/* conductor lobes only */
 } pt_lobe;
 
 typedef struct {
@@ -99,12 +103,17 @@ typedef struct {
     const pt_light *lights;      /* host [n_lights] */
 } pt_scene_desc;
 
-/* ---- camera (camera/projective.py:42-59,137-143,178-232) --------------------------- */
+/* ---- camera (camera/projective.py:42-59; OrthoCamera :65-127; PerspectiveCamera
+ * :137-143,178-232).  EnvironmentCamera is not offered: the reference cannot render with it
+ * (its ray differentials make compute_differential produce NaN). ------------- */
+typedef enum { PT_CAM_PERSPECTIVE = 0, PT_CAM_ORTHO = 1 } pt_cam_kind;
 typedef struct {
     double r2c[16];     /* raster→camera, row-major 4x4 (ProjectiveCamera.r2c.m) */
     double c2w[16];     /* camera→world (c2w.startTransform.m) */
     double dx[3], dy[3];/* dxCam, dyCam */
     double lens_rad, focal_dist;
+    int32_t kind;       /* pt_cam_kind */
+    int32_t _pad;
 } pt_camera;
 
 /* ---- film (film/film.py:108-135) ---------------------------------------------------- */
@@ -123,9 +132,9 @@ typedef struct {
     uint32_t seed;                            /* production stream only (table == NULL) */
 } pt_sampler_desc;
 
-typedef enum { PT_INTEG_DIRECT = 0, PT_INTEG_PATH = 1 } pt_integ_kind;
+typedef enum { PT_INTEG_DIRECT = 0, PT_INTEG_PATH = 1, PT_INTEG_WHITTED = 2 } pt_integ_kind;
 
-/* integrator (integrator/surface/direct.py:36-105, path.py:27-144) */
+/* integrator (integrator/surface/direct.py:36-105, path.py:27-144, whitted.py:16-59) */
 typedef struct {
     int32_t kind;        /* pt_integ_kind */
     int32_t max_depth;

@@ -289,7 +289,7 @@ static inline v3 l2w(const overtex *vx, v3 v) {
 static inline unsigned lobe_flags(int type) {
     switch (type) {
     case PT_LOBE_LAMBERT: case PT_LOBE_OREN_NAYAR: return BDF_REFLECTION | BDF_DIFFUSE;
-    case PT_LOBE_MICROFACET_BLINN: return BDF_REFLECTION | BDF_GLOSSY;
+    case PT_LOBE_MICROFACET_BLINN: case PT_LOBE_MICROFACET_BLINN_COND: return BDF_REFLECTION | BDF_GLOSSY;
     case PT_LOBE_SPEC_REFLECT: return BDF_REFLECTION | BDF_SPECULAR;
     default: return BDF_TRANSMISSION | BDF_SPECULAR;
     }
@@ -335,6 +335,15 @@ static inline double blinn_pdf(double e, v3 wo, v3 wi) {
     return ((e + 1.) * pow(ct, e)) / (2. * PT_PI * 4. * vdot(wo, wh));
 }
 
+/* fr_cond, reflection/utility.py:60-73, one channel; FresnelConductor.__call__ passes |cos| (fresnel.py:40-41) */
+static inline double fr_cond(double cos_i, double eta, double k) {
+    double tmp = (eta * eta + k * k) * cos_i * cos_i;
+    double r_para_sq = (tmp - (2. * eta * cos_i) + 1.) / (tmp + (2. * eta * cos_i) + 1.);
+    tmp = eta * eta + k * k;
+    double r_perp_sq = (tmp - (2. * eta * cos_i) + cos_i * cos_i) / (tmp + (2. * eta * cos_i) + cos_i * cos_i);
+    return .5 * (r_para_sq + r_perp_sq);
+}
+
 /* lobe.f(wo, wi) in the local frame */
 static v3 lobe_f(const pt_lobe *l, v3 wo, v3 wi) {
     v3 R = V(l->R[0], l->R[1], l->R[2]);
@@ -352,6 +361,19 @@ static v3 lobe_f(const pt_lobe *l, v3 wo, v3 wi) {
         if (fabs(wi.z) > fabs(wo.z)) { sa = st_o; tb = st_i / fabs(wi.z); }
         else { sa = st_i; tb = st_o / fabs(wo.z); }
         return vmul(vmul(R, PT_INV_PI), (l->a + l->b * mc * sa * tb));
+    }
+    case PT_LOBE_MICROFACET_BLINN_COND: {       /* torrance.py:200-216 with a Spectrum-valued Fresnel term */
+        double ct_i = wi.z, ct_o = wo.z;
+        if (ct_i == 0. || ct_o == 0.) return V(0, 0, 0);
+        v3 wh = vnormalize(vadd(wi, wo));
+        double ch = fabs(vdot(wi, wh));
+        v3 F = V(fr_cond(ch, l->eta[0], l->k[0]), fr_cond(ch, l->eta[1], l->k[1]), fr_cond(ch, l->eta[2], l->k[2]));
+        double awh = fabs(wh.z), adot = fabs(vdot(wo, wh));
+        double g1 = 2. * awh * fabs(wo.z) / adot, g2 = 2. * awh * fabs(wi.z) / adot;
+        double gm = (g2 < g1) ? g2 : g1;
+        double G = gm < 1. ? gm : 1.;
+        double D = blinn_D(l->c, wh);
+        return vdiv(vmulv(vmul(vmul(R, D), G), F), (4. * ct_i * ct_o));
     }
     case PT_LOBE_MICROFACET_BLINN: {            /* torrance.py:200-216 */
         double ct_i = wi.z, ct_o = wo.z;
@@ -377,7 +399,7 @@ static double lobe_pdf(const pt_lobe *l, v3 wo, v3 wi) {
     case PT_LOBE_LAMBERT: case PT_LOBE_OREN_NAYAR:
         if (wo.z * wi.z > 0.) return fabs(wi.z) * PT_INV_PI;
         return 0.;
-    case PT_LOBE_MICROFACET_BLINN:
+    case PT_LOBE_MICROFACET_BLINN: case PT_LOBE_MICROFACET_BLINN_COND:
         if (wi.z * wo.z <= 0.) return 0.;
         return blinn_pdf(l->c, wo, wi);
     default:
@@ -402,7 +424,7 @@ static double lobe_sample_f(const pt_lobe *l, v3 wo, double u1, double u2, v3 *w
         *f_out = lobe_f(l, wo, wi);
         return lobe_pdf(l, wo, wi);
     }
-    case PT_LOBE_MICROFACET_BLINN: {            /* torrance.py:218-223 + Blinn.sample_f :72-93 */
+    case PT_LOBE_MICROFACET_BLINN: case PT_LOBE_MICROFACET_BLINN_COND: {   /* torrance.py:218-223 + Blinn.sample_f :72-93 */
         double e = l->c;
         double ct = pow(u1, 1. / (e + 1));
         double st = sqrt(max0(1. - ct * ct));
@@ -745,6 +767,8 @@ static int make_layout(const oscene *s, const pt_integrator_desc *ig, olayout *L
             L->d_bcom[i] = o1; o1 += ns; L->d_bdir[i] = o2; o2 += 2 * ns;
         }
         L->dims = 5 + n1 + 2 * n2;
+    } else if (ig->kind == PT_INTEG_WHITTED) {
+        L->dims = 5;                                   /* no request_samples (whitted.py) */
     } else {
         int o1 = 5, o2 = 5 + 12;
         for (int i = 0; i < 3; i++) {
@@ -791,6 +815,7 @@ static void gen_sample_row(const pt_sampler_desc *sp, const olayout *L, const pt
     row[2] = hash_uniform(sid, 0x10000u + 2);
     row[3] = hash_uniform(sid, 0x10000u + 3);
     row[4] = 0.;   /* time = lerp(t, s_open, s_close) with s_open == s_close == 0 in every config */
+    if (ig->kind == PT_INTEG_WHITTED) return;
     if (ig->kind == PT_INTEG_PATH) {
         for (int k = 5; k < L->dims; k++) row[k] = hash_uniform(sid, 0x10000u + (uint32_t)k);
         return;
@@ -847,6 +872,10 @@ static void camera_ray(const pt_camera *cam, const double *row, oray *r) {
     v3 p_cam = xf4_point(cam->r2c, V(row[0], row[1], 0.));
     v3 o = V(0, 0, 0);
     v3 d = vnormalize(p_cam);
+    if (cam->kind == PT_CAM_ORTHO) {               /* OrthoCamera.generate_ray, camera/projective.py:80-108 */
+        o = p_cam;
+        d = V(0., 0., 1.);
+    }
     if (cam->lens_rad > 0.) {
         double lu, lv;
         concentric_sample_disk(row[2], row[3], &lu, &lv);
@@ -858,6 +887,12 @@ static void camera_ray(const pt_camera *cam, const double *row, oray *r) {
     }
     r->o = xf4_point(cam->c2w, o);
     r->d = xf_vec(cam->c2w, d);
+    if (cam->kind == PT_CAM_ORTHO) {
+        /* OrthoCamera.generate_ray_differential (projective.py:110-125) transforms the ray that
+         * generate_ray already took to world space by c2w a SECOND time (Q14) */
+        r->o = xf4_point(cam->c2w, r->o);
+        r->d = xf_vec(cam->c2w, r->d);
+    }
     r->mint = 0.; r->maxt = PT_INF;
 }
 
@@ -894,6 +929,40 @@ static v3 li_direct(octx *c, const pt_integrator_desc *ig, const olayout *Lo, co
         /* specular_reflect: BSDF.sample_f(wo, rng-sample, REFLECTION|SPECULAR) */
         v3 wi, f; unsigned tp;
         /* the rng() draws only choose among >= 2 specular-reflection lobes; a material has at most one */
+        double pdf = bsdf_sample_f(&vx, wo, 0., 0., 0., BDF_REFLECTION | BDF_SPECULAR, &wi, &tp, &f);
+        if (!(pdf > 0. && !util_is_black(f) && fabs(vdot(wi, vx.nn)) != 0.)) break;
+        T = vmulv(T, vdiv(vmul(f, fabs(vdot(wi, vx.nn))), pdf));
+        ray.o = vx.p; ray.d = wi; ray.mint = vx.rEps; ray.maxt = PT_INF;
+        if (!closest(c, &ray, &hit)) { L = vadd(L, vmulv(T, lights_le(s))); break; }
+    }
+    return L;
+}
+
+/* WhittedIntegrator.li (integrator/surface/whitted.py:26-59) as a loop over the specular-reflection
+ * chain, like li_direct.  Every light is sampled once with LightSample.from_rand(rng) (3 draws, the
+ * third unused), no MIS; specular_reflect / specular_transmit each draw 3 more (integrator/
+ * utility.py:128,164).  Along the reflect chain — the only part that contributes (Q5) — the vertex
+ * at depth d therefore starts at draw d * (3 nL + 3).  bsdf.f runs with the default flags (ALL). */
+static v3 li_whitted(octx *c, const pt_integrator_desc *ig, uint32_t sid, oray ray, ohit hit) {
+    const oscene *s = c->s;
+    v3 L = V(0, 0, 0), T = V(1, 1, 1);
+    for (int depth = 0;; depth++) {
+        overtex vx;
+        make_vertex(s, &ray, &hit, &vx);
+        v3 wo = vneg(ray.d);
+        uint32_t k = (uint32_t)depth * (3u * (uint32_t)s->n_lights + 3u);
+        v3 Lsum = V(0, 0, 0);
+        for (int i = 0; i < s->n_lights; i++, k += 3) {
+            olsample ls;
+            light_sample_l(&s->lights[i], vx.p, vx.rEps, hash_uniform(sid, k), hash_uniform(sid, k + 1), &ls);
+            if (spec_is_black(ls.Li) || ls.pdf == 0.) continue;
+            v3 f = bsdf_f(&vx, wo, ls.wi, BDF_ALL);
+            if (!spec_is_black(f) && !occluded(c, &ls.shadow))
+                Lsum = vadd(Lsum, vdiv(vmul(vmul(vmulv(f, ls.Li), fabs(vdot(ls.wi, vx.nn))), 1.), ls.pdf));
+        }
+        L = vadd(L, vmulv(T, Lsum));
+        if (!(depth + 1 < ig->max_depth)) break;
+        v3 wi, f; unsigned tp;
         double pdf = bsdf_sample_f(&vx, wo, 0., 0., 0., BDF_REFLECTION | BDF_SPECULAR, &wi, &tp, &f);
         if (!(pdf > 0. && !util_is_black(f) && fabs(vdot(wi, vx.nn)) != 0.)) break;
         T = vmulv(T, vdiv(vmul(f, fabs(vdot(wi, vx.nn))), pdf));
@@ -1029,8 +1098,10 @@ int pto_render(void *scene, const pt_camera *cam, const pt_film_desc *film, cons
                 if (ig->pretest) hit = occluded(&c, &ray);           /* renderer.py:168 */
                 ohit h;
                 if (hit && closest(&c, &ray, &h)) {                   /* renderer.py:64 */
+                    const uint32_t rsid = sample_table ? sid : mix_seed(sid, sp->seed);
                     if (ig->kind == PT_INTEG_DIRECT) L = li_direct(&c, ig, &Lo, row, ray, h);
-                    else L = li_path(&c, ig, &Lo, row, sample_table ? sid : mix_seed(sid, sp->seed), ray, h);
+                    else if (ig->kind == PT_INTEG_WHITTED) L = li_whitted(&c, ig, rsid, ray, h);
+                    else L = li_path(&c, ig, &Lo, row, rsid, ray, h);
                 }
                 /* guards, renderer.py:185-193 */
                 if (isnan(L.x) || isnan(L.y) || isnan(L.z)) { L = V(0, 0, 0); if (stats) stats->guard_nan++; }

@@ -1,20 +1,23 @@
 """ctypes mirror of include/pytracer_hip.h (struct layouts and enums only)."""
 import ctypes as C
 
-PT_ABI_VERSION = 4
+PT_ABI_VERSION = 5
 PT_MAX_LOBES = 5
 
 PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
 
-PT_LOBE_LAMBERT, PT_LOBE_OREN_NAYAR, PT_LOBE_MICROFACET_BLINN, PT_LOBE_SPEC_REFLECT, PT_LOBE_SPEC_TRANSMIT = range(5)
+(PT_LOBE_LAMBERT, PT_LOBE_OREN_NAYAR, PT_LOBE_MICROFACET_BLINN, PT_LOBE_SPEC_REFLECT, PT_LOBE_SPEC_TRANSMIT,
+ PT_LOBE_MICROFACET_BLINN_COND) = range(6)
 PT_LIGHT_DIFFUSE_SPHERE, PT_LIGHT_SPOT, PT_LIGHT_POINT = range(3)
-PT_INTEG_DIRECT, PT_INTEG_PATH = 0, 1
+PT_INTEG_DIRECT, PT_INTEG_PATH, PT_INTEG_WHITTED = 0, 1, 2
+PT_CAM_PERSPECTIVE, PT_CAM_ORTHO = 0, 1
 PT_BVH_SAH, PT_BVH_MIDDLE = 0, 1
 
 
 class pt_lobe(C.Structure):
     _fields_ = [('type', C.c_int32), ('_pad', C.c_int32), ('R', C.c_double * 3),
-                ('a', C.c_double), ('b', C.c_double), ('c', C.c_double)]
+                ('a', C.c_double), ('b', C.c_double), ('c', C.c_double),
+                ('eta', C.c_double * 3), ('k', C.c_double * 3)]
 
 
 class pt_material(C.Structure):
@@ -37,7 +40,7 @@ class pt_scene_desc(C.Structure):
 
 class pt_camera(C.Structure):
     _fields_ = [('r2c', C.c_double * 16), ('c2w', C.c_double * 16), ('dx', C.c_double * 3), ('dy', C.c_double * 3),
-                ('lens_rad', C.c_double), ('focal_dist', C.c_double)]
+                ('lens_rad', C.c_double), ('focal_dist', C.c_double), ('kind', C.c_int32), ('_pad', C.c_int32)]
 
 
 class pt_film_desc(C.Structure):

@@ -242,7 +242,7 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
         const pt_material &m = d->materials[i];
         if (m.n_lobes < 0 || m.n_lobes > PT_MAX_LOBES) return fail(c, PT_ERR_ARG, "material %d: n_lobes", i);
         for (int k = 0; k < m.n_lobes; k++) {
-            if (m.lobes[k].type < 0 || m.lobes[k].type > PT_LOBE_SPEC_TRANSMIT) return fail(c, PT_ERR_ARG, "material %d: lobe type", i);
+            if (m.lobes[k].type < 0 || m.lobes[k].type > PT_LOBE_MICROFACET_BLINN_COND) return fail(c, PT_ERR_ARG, "material %d: lobe type", i);
             spec |= m.lobes[k].type == PT_LOBE_SPEC_REFLECT;
         }
     }
@@ -481,6 +481,8 @@ static int make_layout(const pt_ctx *c, const pt_integrator_desc *ig, Layout *L)
             o2 += 2 * ns;                      // bsdf u_dir (only read by the dead branch of estimate_direct)
         }
         L->dims = 5 + n1 + 2 * n1;
+    } else if (ig->kind == PT_INTEG_WHITTED) {
+        L->dims = 5;                        // WhittedIntegrator requests no samples
     } else {
         int o1 = 5, o2 = 5 + 12;
         for (int i = 0; i < 3; i++) {       // path.py:38-42
@@ -502,7 +504,9 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     if (!c) return PT_ERR_ARG;
     if (!c->have_scene) return fail(c, PT_ERR_NO_SCENE, "pt_render before pt_scene_upload");
     if (!cam || !film || !sp || !ig || !tile) return fail(c, PT_ERR_ARG, "null descriptor");
-    if (ig->kind != PT_INTEG_DIRECT && ig->kind != PT_INTEG_PATH) return fail(c, PT_ERR_ARG, "integrator kind %d", ig->kind);
+    if (ig->kind != PT_INTEG_DIRECT && ig->kind != PT_INTEG_PATH && ig->kind != PT_INTEG_WHITTED)
+        return fail(c, PT_ERR_ARG, "integrator kind %d", ig->kind);
+    if (cam->kind != PT_CAM_PERSPECTIVE && cam->kind != PT_CAM_ORTHO) return fail(c, PT_ERR_ARG, "camera kind %d", cam->kind);
     if (ig->max_depth < 0 || ig->max_depth > 64) return fail(c, PT_ERR_ARG, "max_depth %d", ig->max_depth);
     if (sp->xs < 1 || sp->ys < 1 || sp->x_end < sp->x_start || sp->y_end < sp->y_start) return fail(c, PT_ERR_ARG, "sampler window");
     const int spp = sp->xs * sp->ys;
@@ -532,7 +536,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t per_path = 8 * 8 * 2 + 4 * 2 * 2 + 8 * 3 * 2 + (8 * 11 + 4) * (size_t)std::max(1, ig->kind == PT_INTEG_DIRECT ? c->shadow_per_vertex_direct : 1) + 8 * 8;
+            const size_t per_path = 8 * 8 * 2 + 4 * 2 * 2 + 8 * 3 * 2 + (8 * 11 + 4) * (size_t)std::max(1, ig->kind == PT_INTEG_DIRECT ? c->shadow_per_vertex_direct : (ig->kind == PT_INTEG_WHITTED ? c->sc.n_lights : 1)) + 8 * 8;
             const size_t budget = (free_b + c->ws_bytes) / 2;     // leave half of what is free to the caller
             const long fit = (long)(budget / per_path);
             if (fit < batch) batch = std::max(fit, 1l << 16);
@@ -540,7 +544,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     }
     batch = std::min(batch, total);
     batch = (batch + 63) & ~63l;
-    const int spv = ig->kind == PT_INTEG_DIRECT ? std::max(c->shadow_per_vertex_direct, 1) : 1;
+    const int spv = ig->kind == PT_INTEG_DIRECT ? std::max(c->shadow_per_vertex_direct, 1)
+                    : (ig->kind == PT_INTEG_WHITTED ? std::max(c->sc.n_lights, 1) : 1);
     // chunk-group size of the segmented queues: up to 64 chunks (the 4096-entry sort window), fewer
     // for small batches so that every region still gets several groups
     int gshift = 0;

@@ -155,7 +155,8 @@ __device__ __forceinline__ d3 l2w(const Vertex &vx, d3 v) {
 __device__ __forceinline__ unsigned lobe_flags(int type) {
     // Lambertian/OrenNayar: REFLECTION|DIFFUSE; Microfacet: REFLECTION|GLOSSY;
     // SpecularReflection: REFLECTION|SPECULAR; SpecularTransmission: TRANSMISSION|SPECULAR
-    const unsigned tab = (5u) | (5u << 5) | (9u << 10) | (17u << 15) | (18u << 20);
+    // (the conductor microfacet lobe, type 5, is REFLECTION|GLOSSY like type 2)
+    const unsigned tab = (5u) | (5u << 5) | (9u << 10) | (17u << 15) | (18u << 20) | (9u << 25);
     return (tab >> (5 * type)) & 31u;
 }
 // BDF.match_flag, bdf.py:166-170
@@ -179,6 +180,15 @@ __device__ inline double fresnel_dielectric(double cosi, double eta_i, double et
     if (st >= 1.) return 1.;
     double ct = sqrt(max0(1. - st * st));
     return fr_diel(fabs(ci), ct, ei, et);
+}
+
+// fr_cond, reflection/utility.py:60-73, one channel; FresnelConductor.__call__ passes |cos| (fresnel.py:40-41)
+__device__ __forceinline__ double fr_cond(double cos_i, double eta, double k) {
+    double tmp = (eta * eta + k * k) * cos_i * cos_i;
+    double r_para_sq = (tmp - (2. * eta * cos_i) + 1.) / (tmp + (2. * eta * cos_i) + 1.);
+    tmp = eta * eta + k * k;
+    double r_perp_sq = (tmp - (2. * eta * cos_i) + cos_i * cos_i) / (tmp + (2. * eta * cos_i) + cos_i * cos_i);
+    return .5 * (r_para_sq + r_perp_sq);
 }
 
 // reflection/utility.py:31-42
@@ -218,17 +228,23 @@ __device__ inline d3 lobe_f(const pt_lobe &l, d3 wo, d3 wi) {
         else { sa = st_i; tb = st_o / fabs(wo.z); }
         return (R * PT_INV_PI) * (l.a + l.b * mc * sa * tb);
     }
-    case PT_LOBE_MICROFACET_BLINN: {   // torrance.py:200-216, Blinn.D :69-70
+    case PT_LOBE_MICROFACET_BLINN:
+    case PT_LOBE_MICROFACET_BLINN_COND: {   // torrance.py:200-216, Blinn.D :69-70
         double ct_i = wi.z, ct_o = wo.z;
         if (ct_i == 0. || ct_o == 0.) return mk3(0, 0, 0);
         d3 wh = normalize3(wi + wo);
         double ct_h = dot3(wi, wh);
-        double F = fresnel_dielectric(ct_h, l.a, l.b);
         double awh = fabs(wh.z), adot = fabs(dot3(wo, wh));
         double g1 = 2. * awh * fabs(wo.z) / adot, g2 = 2. * awh * fabs(wi.z) / adot;
         double gm = (g2 < g1) ? g2 : g1;
         double G = (gm < 1.) ? gm : 1.;
         double D = (l.c + 2) * PT_INV_2PI * pow(awh, l.c);
+        if (l.type == PT_LOBE_MICROFACET_BLINN_COND) {   // Spectrum-valued Fresnel term (MetalMaterial)
+            const double ch = fabs(ct_h);
+            d3 F = mk3(fr_cond(ch, l.eta[0], l.k[0]), fr_cond(ch, l.eta[1], l.k[1]), fr_cond(ch, l.eta[2], l.k[2]));
+            return (((R * D) * G) * F) / (4. * ct_i * ct_o);
+        }
+        double F = fresnel_dielectric(ct_h, l.a, l.b);
         return (((R * D) * G) * F) / (4. * ct_i * ct_o);
     }
     default:   // specular lobes evaluate to 0, bdf.py:241-246,274-279
@@ -243,6 +259,7 @@ __device__ inline double lobe_pdf(const pt_lobe &l, d3 wo, d3 wi) {
     case PT_LOBE_OREN_NAYAR:
         return (wo.z * wi.z > 0.) ? fabs(wi.z) * PT_INV_PI : 0.;
     case PT_LOBE_MICROFACET_BLINN:
+    case PT_LOBE_MICROFACET_BLINN_COND:
         if (wi.z * wo.z <= 0.) return 0.;
         return blinn_pdf(l.c, wo, wi);
     default:
@@ -268,7 +285,8 @@ __device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, doubl
         f_out = lobe_f(l, wo, wi);
         return lobe_pdf(l, wo, wi);
     }
-    case PT_LOBE_MICROFACET_BLINN: {   // torrance.py:218-223, Blinn.sample_f :72-93
+    case PT_LOBE_MICROFACET_BLINN:
+    case PT_LOBE_MICROFACET_BLINN_COND: {   // torrance.py:218-223, Blinn.sample_f :72-93
         double e = l.c;
         double ct = pow(u1, 1. / (e + 1));
         double st = sqrt(max0(1. - ct * ct));

@@ -525,6 +525,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
     d3 p_cam = xf4_point(rc.cam.r2c, mk3(ix, iy, 0.));
     d3 o = mk3(0, 0, 0);
     d3 d = normalize3(p_cam);
+    if (rc.cam.kind == PT_CAM_ORTHO) {   // OrthoCamera.generate_ray, camera/projective.py:80-108
+        o = p_cam;
+        d = mk3(0., 0., 1.);
+    }
     if (rc.cam.lens_rad > 0.) {
         double a, b;
         concentric_sample_disk(lu, lv, a, b);
@@ -536,6 +540,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
     }
     o = xf4_point(rc.cam.c2w, o);
     d = xf_vec(rc.cam.c2w, d);
+    if (rc.cam.kind == PT_CAM_ORTHO) {
+        // OrthoCamera.generate_ray_differential (projective.py:110-125) transforms the ray that
+        // generate_ray already took to world space by c2w a SECOND time (Q14)
+        o = xf4_point(rc.cam.c2w, o);
+        d = xf_vec(rc.cam.c2w, d);
+    }
     const long S = q.stride;
     const long e = seg_entry(i, gshift, q.seg);
     q.rays[e] = o.x; q.rays[S + e] = o.y; q.rays[2 * S + e] = o.z;
@@ -579,6 +589,21 @@ __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, con
         double weight = ff * ff / (ff * ff + g * g);   // power_heuristic, montecarlo/utility.py:33-42
         c = (f * ls.Li) * (adot * weight / ls.pdf);
     }
+    shadow = ls.shadow;
+    return true;
+}
+
+// One light of WhittedIntegrator.li (integrator/surface/whitted.py:44-53): no MIS, bsdf.f with the
+// default flags, Spectrum.is_black tests.  Returns true if a shadow ray must be traced.
+__device__ inline bool estimate_whitted(const DScene &sc, const pt_light &lt, const Vertex &vx, d3 wo, double u0,
+                                        double u1, Ray &shadow, d3 &c) {
+    LightSample ls;
+    if (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) sphere_light_sample_l(lt, vx.p, vx.rEps, u0, u1, ls);
+    else delta_light_sample_l(lt, vx.p, vx.rEps, ls);
+    if (spec_is_black(ls.Li) || ls.pdf == 0.) return false;
+    d3 f = bsdf_f(vx, wo, ls.wi, BDF_ALL);
+    if (spec_is_black(f)) return false;
+    c = (((f * ls.Li) * fabs(dot3(ls.wi, vx.nn))) * 1.) / ls.pdf;   // x transmittance (= 1) / pdf
     shadow = ls.shadow;
     return true;
 }
@@ -646,7 +671,22 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
         }
         bool cont = false;
         Ray nray;
-        if (KIND == PT_INTEG_DIRECT) {
+        if (KIND == PT_INTEG_WHITTED) {
+            // every light once with LightSample.from_rand(rng): 3 draws each, then 3 for specular_reflect
+            // (integrator/utility.py:128); along the reflect chain depth d starts at draw d (3 nL + 3)
+            uint32_t k = (uint32_t)level * (3u * (uint32_t)sc.n_lights + 3u);
+            for (int li = 0; li < sc.n_lights; li++, k += 3) {
+                bool need = false;
+                Ray sr;
+                d3 c = mk3(0, 0, 0);
+                if (hit) {
+                    need = estimate_whitted(sc, sc.lights[li], vx, wo, hash_uniform(ss.msid, k),
+                                            hash_uniform(ss.msid, k + 1), sr, c);
+                    c = T * c;
+                }
+                push_shadow(sh, region, need, sr, c, slot);
+            }
+        } else if (KIND == PT_INTEG_DIRECT) {
             // uniform_sample_all_lights, integrator/utility.py:45-77
             for (int li = 0; li < sc.n_lights; li++) {
                 const int ns = rc.lay.d_ns[li], off = rc.lay.d_lpos[li];
@@ -665,6 +705,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                     push_shadow(sh, region, need, sr, c, slot);
                 }
             }
+        }
+        if (KIND != PT_INTEG_PATH) {
+            // specular_reflect, integrator/utility.py:120-155 (shared by Direct and Whitted)
             if (hit && (level + 1 < rc.ig.max_depth)) {
                 d3 wi, f;
                 double pdf = bsdf_sample_f(vx, wo, 0., 0., 0., BDF_REFLECTION | BDF_SPECULAR, wi, f);
@@ -792,6 +835,8 @@ hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene 
     grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
     if (kind == PT_INTEG_DIRECT)
         hipLaunchKernelGGL((k_shade<PT_INTEG_DIRECT>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st);
+    else if (kind == PT_INTEG_WHITTED)
+        hipLaunchKernelGGL((k_shade<PT_INTEG_WHITTED>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st);
     else
         hipLaunchKernelGGL((k_shade<PT_INTEG_PATH>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st);
     return hipGetLastError();

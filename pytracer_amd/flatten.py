@@ -46,7 +46,8 @@ def _blinn_exponent(rough):
 def lobes_from_params(kind, **p):
     """Ordered lobe list [(type, R[3], a, b, c)] for one material record.
 
-    kind: 'matte' | 'uber' | 'plastic' | 'mirror' | 'glass'
+    kind: 'matte' | 'uber' | 'plastic' | 'mirror' | 'glass' | 'metal'
+    (a conductor lobe carries two more entries: eta[3], k[3])
     """
     out = []
     if kind == 'matte':                         # material.py:122-141
@@ -93,6 +94,9 @@ def lobes_from_params(kind, **p):
         t = _clip(_spec(p['Kt']))
         if not _is_black(t):
             out.append((A.PT_LOBE_SPEC_TRANSMIT, t, 1., ior, 0.))
+    elif kind == 'metal':                       # material.py:242-258: Microfacet(Spectrum(1.), FresnelConductor, Blinn)
+        out.append((A.PT_LOBE_MICROFACET_BLINN_COND, np.ones(3), 0., 0., _blinn_exponent(float(p['roughness'])),
+                    _spec(p['eta']), _spec(p['k'])))
     else:
         raise NotImplementedError('material kind %r is outside the supported hot path' % (kind,))
     if len(out) > A.PT_MAX_LOBES:
@@ -123,16 +127,22 @@ def material_params(mat):
         return 'mirror', dict(Kr=_tex(mat.Kr))
     if nm == 'GlassMaterial':
         return 'glass', dict(Kr=_tex(mat.Kr), Kt=_tex(mat.Kt), index=_tex(mat.index))
+    if nm == 'MetalMaterial':
+        return 'metal', dict(eta=_tex(mat.eta), k=_tex(mat.k), roughness=_tex(mat.roughness))
     raise NotImplementedError('material %s is outside the supported hot path' % nm)
 
 
 def _pack_material(lobes):
     m = A.pt_material()
     m.n_lobes = len(lobes)
-    for i, (tp, R, a, b, c) in enumerate(lobes):
+    for i, lobe in enumerate(lobes):
+        tp, R, a, b, c = lobe[:5]
         m.lobes[i].type = tp
         m.lobes[i].R[:] = [float(x) for x in R]
         m.lobes[i].a, m.lobes[i].b, m.lobes[i].c = float(a), float(b), float(c)
+        if len(lobe) > 5:
+            m.lobes[i].eta[:] = [float(x) for x in lobe[5]]
+            m.lobes[i].k[:] = [float(x) for x in lobe[6]]
     return m
 
 
@@ -274,6 +284,8 @@ class FlatScene(object):
         direct.py:46-62 or path.py:34-42)."""
         if integ_kind == A.PT_INTEG_PATH:
             return 35
+        if integ_kind == A.PT_INTEG_WHITTED:
+            return 5                            # WhittedIntegrator requests no samples (whitted.py)
         return 5 + 6 * sum(self.light_ns())
 
 
@@ -319,7 +331,7 @@ def flatten_scene(scene):
     return FlatScene(nb, nm, tv, tm, tf, lobes, [light_record(l) for l in scene.lights])
 
 
-_MAT_KINDS = {0: 'matte', 1: 'uber', 2: 'plastic', 3: 'mirror', 4: 'glass'}
+_MAT_KINDS = {0: 'matte', 1: 'uber', 2: 'plastic', 3: 'mirror', 4: 'glass', 5: 'metal'}
 
 
 def flat_scene_from_npz(d):
@@ -339,8 +351,9 @@ def flat_scene_from_npz(d):
 # --------------------------------------------------------------------------------------
 # camera / film / sampler / integrator descriptors
 # --------------------------------------------------------------------------------------
-def camera_desc(r2c, c2w, dx, dy, lens_rad=0., focal_dist=0.):
+def camera_desc(r2c, c2w, dx, dy, lens_rad=0., focal_dist=0., kind=A.PT_CAM_PERSPECTIVE):
     c = A.pt_camera()
+    c.kind = int(kind)
     c.r2c[:] = [float(x) for x in np.asarray(r2c, np.float64).ravel()]
     c.c2w[:] = [float(x) for x in np.asarray(c2w, np.float64).ravel()]
     c.dx[:] = [float(x) for x in dx]
@@ -350,13 +363,15 @@ def camera_desc(r2c, c2w, dx, dy, lens_rad=0., focal_dist=0.):
 
 
 def camera_desc_from_object(camera):
-    if type(camera).__name__ != 'PerspectiveCamera':
-        raise NotImplementedError('only PerspectiveCamera is on the supported hot path')
+    kinds = {'PerspectiveCamera': A.PT_CAM_PERSPECTIVE, 'OrthoCamera': A.PT_CAM_ORTHO}
+    if type(camera).__name__ not in kinds:
+        raise NotImplementedError('only PerspectiveCamera and OrthoCamera are on the supported hot path '
+                                  '(the reference itself cannot render with EnvironmentCamera)')
     c2w = camera.c2w
     if getattr(c2w, 'animated', False):
         raise NotImplementedError('animated camera transforms are outside the supported hot path')
     return camera_desc(camera.r2c.m, c2w.startTransform.m, camera.dxCam, camera.dyCam,
-                       camera.lens_rad, camera.focal_dist)
+                       camera.lens_rad, camera.focal_dist, kinds[type(camera).__name__])
 
 
 def film_desc(x_res, y_res, win, xw, yw, table):
@@ -379,7 +394,7 @@ def film_desc_from_object(film):
 
 def camera_film_from_npz(d):
     cam = camera_desc(d['cam_r2c'], d['cam_c2w'], d['cam_dx'], d['cam_dy'], float(d['cam_lens_rad']),
-                      float(d['cam_focal']))
+                      float(d['cam_focal']), int(d['cam_kind']) if 'cam_kind' in d else A.PT_CAM_PERSPECTIVE)
     film = film_desc(d['film_res'][0], d['film_res'][1], d['film_win'], d['filt_w'][0], d['filt_w'][1],
                      d['filt_table'])
     return cam, film
@@ -415,6 +430,8 @@ def integrator_desc_from_object(integ, pretest=False):
         return integrator_desc(A.PT_INTEG_DIRECT, integ.max_depth, pretest)
     if nm == 'PathIntegrator':
         return integrator_desc(A.PT_INTEG_PATH, integ.max_depth, pretest)
+    if nm == 'WhittedIntegrator':
+        return integrator_desc(A.PT_INTEG_WHITTED, integ.max_depth, pretest)
     raise NotImplementedError('integrator %s is outside the supported hot path' % nm)
 
 

@@ -23,7 +23,7 @@ import pytracer.geometry as geo  # noqa: E402
 from pytracer import Spectrum, EPS  # noqa: E402
 from pytracer.aggregate import Intersection, BVH, GeometricPrimitive  # noqa: E402
 from pytracer.sampler import StratifiedSampler, Sample  # noqa: E402
-from pytracer.integrator import DirectLightingIntegrator, PathIntegrator  # noqa: E402
+from pytracer.integrator import DirectLightingIntegrator, PathIntegrator, WhittedIntegrator  # noqa: E402
 from pytracer.renderer import SamplerRenderer  # noqa: E402
 from pytracer.reflection import BSDF, BDFType  # noqa: E402
 import pytracer.light.light as light_mod  # noqa: E402
@@ -116,6 +116,9 @@ def dump_scene(scene, camera=None):
                              Kr=np.array(mt.Kr(None)), Kt=np.array(mt.Kt(None)),
                              roughness=float(mt.roughness(None)), opacity=np.array(mt.opacity(None)),
                              eta=float(mt.eta(None))))
+        elif nm == 'MetalMaterial':
+            mrec.append(dict(kind=5, eta=np.array(mt.eta(None)), k=np.array(mt.k(None)),
+                             roughness=float(mt.roughness(None))))
         elif nm == 'MirrorMaterial':
             mrec.append(dict(kind=3, Kr=np.array(mt.Kr(None))))
         elif nm == 'GlassMaterial':
@@ -170,7 +173,16 @@ def dump_scene(scene, camera=None):
 
 def dump_camera(camera):
     film = camera.film
-    return dict(cam_r2c=np.array(camera.r2c.m), cam_c2w=np.array(camera.c2w.startTransform.m),
+    kind = {'PerspectiveCamera': 0, 'OrthoCamera': 1, 'EnvironmentCamera': 2}[type(camera).__name__]
+    if kind == 2:
+        return dict(cam_kind=np.int32(2), cam_r2c=np.eye(4), cam_c2w=np.array(camera.c2w.startTransform.m),
+                    cam_dx=np.zeros(3), cam_dy=np.zeros(3), cam_lens_rad=np.float64(0.), cam_focal=np.float64(0.),
+                    film_res=np.array([film.xResolution, film.yResolution], np.int32),
+                    film_win=np.array([film.xPixel_start, film.xPixel_cnt, film.yPixel_start, film.yPixel_cnt],
+                                      np.int32),
+                    filt_w=np.array([film.filter.xw, film.filter.yw], np.float64),
+                    filt_table=np.array(film.filter_table, np.float64))
+    return dict(cam_kind=np.int32(kind), cam_r2c=np.array(camera.r2c.m), cam_c2w=np.array(camera.c2w.startTransform.m),
                 cam_dx=np.array(camera.dxCam), cam_dy=np.array(camera.dyCam),
                 cam_lens_rad=np.float64(camera.lens_rad), cam_focal=np.float64(camera.focal_dist),
                 film_res=np.array([film.xResolution, film.yResolution], np.int32),
@@ -448,7 +460,8 @@ class C4Mini(object):
     def __init__(self, variant='lights'):
         from pytracer.shape import Sphere, create_triangle_mesh
         from pytracer.transform import Transform
-        from pytracer.material import MatteMaterial, PlasticMaterial, MirrorMaterial, GlassMaterial, UberMaterial
+        from pytracer.material import (MatteMaterial, PlasticMaterial, MirrorMaterial, GlassMaterial, UberMaterial,
+                                       MetalMaterial)
         from pytracer.texture import ConstantTexture
         from pytracer.light import SpotLight, PointLight, DiffuseAreaLight
         from pytracer.scene import Scene
@@ -466,6 +479,13 @@ class C4Mini(object):
                                 ConstantTexture(0.05)),
                 MatteMaterial(ConstantTexture(Spectrum([.5, .5, .5])), ConstantTexture(20.))]    # Oren-Nayar wall
         nmesh = 2
+        if variant == 'xtra':
+            c3 = lambda v: ConstantTexture(Spectrum(v))
+            mats = [MetalMaterial(c3([.2, .9, 1.1]), c3([3.9, 2.4, 2.2]), ConstantTexture(.08)),
+                    MirrorMaterial(c3([.9, .8, .7])),
+                    GlassMaterial(c3([.8, .8, .8]), c3([.7, .9, .7]), ConstantTexture(1.5)),
+                    MatteMaterial(c3([.5, .5, .5]), ConstantTexture(0.))]
+            nmesh = 3
         if variant == 'spec':
             # specular chains: a mirror, glass, and an Uber material with a specular-reflection component
             c3 = lambda v: ConstantTexture(Spectrum(v))
@@ -492,21 +512,34 @@ class C4Mini(object):
         lights = [SpotLight(spot_l2w, Spectrum(200.), 30., 25.),
                   PointLight(Transform.translate(geo.Vector(8., -6., -12.)), Spectrum(150.)),
                   DiffuseAreaLight(st, Spectrum(10.), 2, sph)]
-        if variant == 'spec':
+        if variant in ('spec', 'xtra'):
             lights = lights[1:]
         self.scene = Scene(BVH(prims), lights, None)
 
-    @staticmethod
-    def configure_camera(x_res=50, y_res=50, file_name='tmp.png'):
+    camera_kind = 'perspective'
+
+    def configure_camera(self, x_res=50, y_res=50, file_name='tmp.png'):
         from pytracer.transform import Transform, AnimatedTransform
         from pytracer.filter import LanczosSincFilter
         from pytracer.film import ImageFilm
-        from pytracer.camera import PerspectiveCamera
+        from pytracer.camera import PerspectiveCamera, OrthoCamera, EnvironmentCamera
         fil = LanczosSincFilter(4., 4., 3.)
         film = ImageFilm(x_res, y_res, fil, [0., 1., 0., 1.], file_name)
         c_trans = Transform.translate(geo.Vector(0., 0., -30.))
-        return PerspectiveCamera(AnimatedTransform(c_trans, 0., c_trans, 0.), [0., 1., 0., 1.], 0., 0., 0., 1e100, 60.,
-                                 film)
+        at = AnimatedTransform(c_trans, 0., c_trans, 0.)
+        k = self.camera_kind
+        if k == 'perspective':
+            return PerspectiveCamera(at, [0., 1., 0., 1.], 0., 0., 0., 1e100, 60., film)
+        if k == 'perspective_lens':       # thin lens: camera/projective.py:196-210
+            return PerspectiveCamera(at, [-1., 1., -1., 1.], 0., 0., .8, 30., 60., film)
+        if k == 'ortho':
+            return OrthoCamera(at, [-12., 12., -12., 12.], 0., 0., 0., 1e100, film)
+        if k == 'ortho_lens':
+            return OrthoCamera(at, [-12., 12., -12., 12.], 0., 0., .6, 30., film)
+        if k == 'environment':
+            e_trans = Transform.translate(geo.Vector(0., 0., -8.))
+            return EnvironmentCamera(AnimatedTransform(e_trans, 0., e_trans, 0.), 0., 0., film)
+        raise ValueError(k)
 
 
 def gen_c4mini():
@@ -664,7 +697,34 @@ def gen_loop():
     print('loop: head base %d verts %d tris' % (len(d['head_P']), len(d['head_idx']) // 3))
 
 
-ALL = dict(loop=gen_loop, specmini=gen_specmini, c2=gen_c2, c4mini=gen_c4mini, scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
+def gen_xtra():
+    """§8(f) rank 2: WhittedIntegrator (whitted.py:16-59), MetalMaterial (FresnelConductor),
+    OrthoCamera / EnvironmentCamera and the thin-lens branches of the projective cameras."""
+    runs = [('whitted', 'xtra', 'perspective', WhittedIntegrator(), 24, 24),
+            ('metal_direct', 'xtra', 'perspective', DirectLightingIntegrator(), 20, 20),
+            ('metal_path', 'xtra', 'perspective', PathIntegrator(max_depth=5), 16, 16),
+            ('lens_direct', 'lights', 'perspective_lens', DirectLightingIntegrator(), 16, 16),
+            ('ortho_direct', 'lights', 'ortho', DirectLightingIntegrator(), 16, 16),
+            ('ortholens_whitted', 'xtra', 'ortho_lens', WhittedIntegrator(), 16, 16)]
+    # EnvironmentCamera is not among them: with this scene the reference raises ValueError for every seed
+    # tried (Camera.generate_ray_differential's shifted rays make DifferentialGeometry.compute_differential
+    # produce NaN, which geometry.Vector refuses) — ('env_direct', 'lights', 'environment', Direct, 24, 12)
+    for name, variant, camk, integ, xr, yr in runs:
+        model = C4Mini(variant)
+        model.camera_kind = camk
+        t = time.time()
+        cam = model.configure_camera(x_res=xr, y_res=yr, file_name='/tmp/_fixture.png')
+        sc = dump_scene(model.scene, cam)
+        d = instrumented_render(model, xr, yr, 1, 1, integ, seed=21)
+        d.update(sc)
+        np.savez_compressed(os.path.join(OUT, 'xtra_%s.npz' % name), **d)
+        kinds = d['log_rays'][:, 1].astype(int)
+        print('xtra %s: %.1fs, closest %d any %d (samples %d), sumL %.6f, zero-L %d' % (
+            name, time.time() - t, (kinds == 0).sum(), (kinds == 1).sum(), len(d['L']), d['L'].sum(),
+            int((d['L'].sum(1) == 0).sum())), flush=True)
+
+
+ALL = dict(xtra=gen_xtra, loop=gen_loop, specmini=gen_specmini, c2=gen_c2, c4mini=gen_c4mini, scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)
