@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of kernel variants in ONE process, interleaved rounds (cdna_hip_programming.md §5.4 rule 24).
 
-    python scripts/ab_bench.py --env PT_TRACE_VARIANT=0 --env PT_TRACE_VARIANT=1 [--rounds 3] [--spp 8]
+    python scripts/ab_bench.py --env PT_TRACE_TOP=0 --env PT_TRACE_TOP=1 [--rounds 3] [--spp 8]
 
 Each --env arm gets its own pt_ctx (the knobs are read at context creation); every round renders
 the bench workload once per arm and prints per-stage kernel time (HIP events) per arm."""
