@@ -60,7 +60,7 @@ def cpu_baseline(flat, cam, film, integ, res, xs):
     import pytracer_amd as pa
     from pytracer_amd import _abi as A
     osc = O.OracleScene(flat)
-    win = 160                                   # 160x160 pixels x 64 spp ≈ 1.6 M camera samples
+    win = min(320, res)                         # 320x320 pixels x 64 spp ≈ 6.6 M camera samples, ≈10 s
     x0 = (res - win) // 2
     smp = pa.sampler_desc(0, res, 0, res, xs, xs, True, 0)
     tile = pa.tile_desc(x0, x0 + win, x0, x0 + win, 0, xs * xs)

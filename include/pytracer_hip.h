@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 5
+#define PT_ABI_VERSION 6
 
 typedef enum {
     PT_OK = 0,
@@ -210,6 +210,16 @@ int pt_set_profiling(pt_ctx *ctx, int enable);
  * [y][x][3]. */
 int pt_film_resolve(pt_ctx *ctx, const double *film_accum, int32_t x_cnt, int32_t y_cnt,
                     double *rgb, void *stream);
+
+/* replaces: the array conversion at the top of imageio.write_image (utility/imageio.py:60-65):
+ * per channel c, coef = max(rgb[:,:,c]); if coef != 0: rgb[:,:,c] = (255 * rgb[:,:,c]) / coef;
+ * then rgb.astype('uint8') (truncation; the same binary64 operations, so the bytes are those numpy
+ * produces from the same rgb).  rgb device [y][x][3] f64 (the output of pt_film_resolve; not
+ * modified) → out device [y][x][3] u8, ready for PIL.Image.fromarray(..., 'RGB').  Calls on one
+ * context are ordered by their stream; two streams must not run this concurrently on one context
+ * (the three channel maxima live in the context). */
+int pt_film_to_u8(pt_ctx *ctx, const double *rgb, int32_t x_cnt, int32_t y_cnt, uint8_t *out,
+                  void *stream);
 
 /* replaces: BVH.__init__ → _recursive_build → _flatten_tree (aggregate/accelerator/bvh.py:
  * 68-107,152-275,277-293, with _partition :110-120, _insertion_sort :123-130,

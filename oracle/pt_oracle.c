@@ -1064,6 +1064,28 @@ int pto_film_resolve(const double *acc, int32_t x_cnt, int32_t y_cnt, double *rg
     return PT_OK;
 }
 
+/* The array conversion of imageio.write_image (utility/imageio.py:60-65): per channel
+ * coef = np.max(rgb[:,:,c]) (NaN propagates), `if not coef == 0.: rgb = (255. * rgb) / coef`, then
+ * rgb.astype('uint8'), which on x86-64 is the C conversion through a 32-bit integer (low byte kept;
+ * out of range / NaN → 0x80000000 → 0). */
+int pto_film_to_u8(const double *rgb, int32_t x_cnt, int32_t y_cnt, uint8_t *out) {
+    const size_t n = (size_t)x_cnt * y_cnt;
+    for (int c = 0; c < 3; c++) {
+        double coef = n ? rgb[c] : 0.;
+        for (size_t i = 1; i < n; i++) {
+            const double v = rgb[3 * i + c];
+            if (v != v || v > coef) { if (!(coef != coef)) coef = v; }
+        }
+        for (size_t i = 0; i < n; i++) {
+            double v = rgb[3 * i + c];
+            if (!(coef == 0.)) v = (255. * v) / coef;
+            int32_t q = (v > -2147483649. && v < 2147483648.) ? (int32_t)v : (int32_t)0x80000000u;
+            out[3 * i + c] = (uint8_t)(q & 255);
+        }
+    }
+    return PT_OK;
+}
+
 /* ----------------------------------------------------------------------------------
  * SamplerRendererTask.__call__ (renderer/renderer.py:132-198): same argument meaning as
  * pt_render, host pointers.

@@ -13,7 +13,7 @@ if os.environ.get('PYTRACER_HIP_LIB'):        # kernel A/B experiments only (scr
     LIB_PATH = os.path.abspath(os.environ['PYTRACER_HIP_LIB'])
 
 EXPORTS = ('pt_version', 'pt_ctx_create', 'pt_ctx_destroy', 'pt_last_error', 'pt_scene_upload', 'pt_intersect',
-           'pt_render', 'pt_film_resolve', 'pt_set_profiling', 'pt_bvh_build', 'pt_build_last_error',
+           'pt_render', 'pt_film_resolve', 'pt_film_to_u8', 'pt_set_profiling', 'pt_bvh_build', 'pt_build_last_error',
            'pt_loop_subdiv', 'pt_subdiv_last_error')
 
 _lib = None
@@ -50,6 +50,7 @@ def lib():
                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(A.pt_stats), C.c_void_p]
         L.pt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pt_film_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.pt_film_to_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.pt_build_last_error.restype = C.c_char_p
@@ -154,3 +155,13 @@ class Context(object):
         rgb = torch.empty((y, x, 3), dtype=torch.float64, device=film_accum.device)
         self._check(lib().pt_film_resolve(self._h, film_accum.data_ptr(), x, y, rgb.data_ptr(), self._stream(stream)))
         return rgb
+
+    def film_to_u8(self, rgb, stream=None):
+        """imageio.write_image's 8-bit conversion (utility/imageio.py:60-65) of a resolved film:
+        torch float64 cuda [y, x, 3] → torch uint8 cuda [y, x, 3]."""
+        import torch
+        assert rgb.is_cuda and rgb.dtype == torch.float64 and rgb.is_contiguous() and rgb.dim() == 3 and rgb.shape[2] == 3
+        out = torch.empty(tuple(rgb.shape), dtype=torch.uint8, device=rgb.device)
+        self._check(lib().pt_film_to_u8(self._h, rgb.data_ptr(), rgb.shape[1], rgb.shape[0], out.data_ptr(),
+                                        self._stream(stream)))
+        return out

@@ -102,7 +102,8 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     c->use_top = -1;
     if (const char *e = getenv("PT_TRACE_TOP")) c->use_top = atoi(e);
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
-    CREATE_CHK(hipMalloc((void **)&c->d_counters, PT_CNT_SHARDS * CNT_COUNT * sizeof(unsigned long long)));
+    // + 4 words behind the census shards: the channel maxima of pt_film_to_u8
+    CREATE_CHK(hipMalloc((void **)&c->d_counters, (PT_CNT_SHARDS * CNT_COUNT + 4) * sizeof(unsigned long long)));
     c->ev = new std::vector<hipEvent_t>();
     c->ev_stage = new std::vector<int>();
     *out = c;
@@ -642,5 +643,16 @@ extern "C" int pt_film_resolve(pt_ctx *c, const double *film_accum, int32_t x_cn
     if (!film_accum || !rgb || x_cnt < 0 || y_cnt < 0) return fail(c, PT_ERR_ARG, "film_resolve arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, pt_launch_film_resolve((hipStream_t)stream_, film_accum, (long)x_cnt * y_cnt, rgb));
+    return PT_OK;
+}
+
+extern "C" int pt_film_to_u8(pt_ctx *c, const double *rgb, int32_t x_cnt, int32_t y_cnt, uint8_t *out, void *stream_) {
+    if (!c) return PT_ERR_ARG;
+    if (x_cnt < 0 || y_cnt < 0) return fail(c, PT_ERR_ARG, "film_to_u8 arguments");
+    if ((long)x_cnt * y_cnt == 0) return PT_OK;      // np.max of an empty channel raises in the reference; nothing to write
+    if (!rgb || !out) return fail(c, PT_ERR_ARG, "film_to_u8 arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, pt_launch_film_to_u8((hipStream_t)stream_, rgb, (long)x_cnt * y_cnt,
+                                   c->d_counters + PT_CNT_SHARDS * CNT_COUNT, out));
     return PT_OK;
 }

@@ -125,3 +125,5 @@ hipError_t pt_launch_splat(hipStream_t stream, const RenderConst *rc, const pt_t
                            long base, int nb, const PathState &st, double *film, double *sample_L,
                            unsigned long long *counters);
 hipError_t pt_launch_film_resolve(hipStream_t stream, const double *acc, long npix, double *rgb);
+hipError_t pt_launch_film_to_u8(hipStream_t stream, const double *rgb, long npix, unsigned long long *keys,
+                                unsigned char *out);

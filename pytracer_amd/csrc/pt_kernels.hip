@@ -1058,3 +1058,60 @@ hipError_t pt_launch_film_resolve(hipStream_t stream, const double *acc, long np
     if (grid > 0) hipLaunchKernelGGL(k_film_resolve, dim3(grid), dim3(PT_BLOCK), 0, stream, acc, npix, rgb);
     return hipGetLastError();
 }
+
+// K9 8-bit image: the array conversion of imageio.write_image (utility/imageio.py:60-65).  Pass 1: per-channel
+// maximum.  binary64 values are compared through an order-preserving 64-bit key so that one integer atomic max
+// per wave serves negative values too; a NaN (positive quiet) maps above +inf and so propagates like np.max.
+__device__ inline unsigned long long f64_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ inline double f64_unkey(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void k_chan_max(const double *__restrict__ rgb, long npix,
+                                                       unsigned long long *__restrict__ keys) {
+    unsigned long long m0 = 0, m1 = 0, m2 = 0;      // key 0 is below every finite value and -inf
+    for (long i = (long)blockIdx.x * PT_BLOCK + threadIdx.x; i < npix; i += (long)gridDim.x * PT_BLOCK) {
+        const unsigned long long a = f64_key(rgb[3 * i]), b = f64_key(rgb[3 * i + 1]), c = f64_key(rgb[3 * i + 2]);
+        m0 = a > m0 ? a : m0; m1 = b > m1 ? b : m1; m2 = c > m2 ? c : m2;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = __shfl_xor(m0, o), b = __shfl_xor(m1, o), c = __shfl_xor(m2, o);
+        m0 = a > m0 ? a : m0; m1 = b > m1 ? b : m1; m2 = c > m2 ? c : m2;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(keys, m0); atomicMax(keys + 1, m1); atomicMax(keys + 2, m2);
+    }
+}
+
+// Pass 2: `if coef != 0: v = (255 * v) / coef`, then ndarray.astype('uint8'): the C conversion numpy compiles to on
+// x86-64 (truncate to a 32-bit integer, keep the low byte; out-of-range and NaN give the "integer indefinite"
+// 0x80000000, i.e. byte 0).
+__global__ __launch_bounds__(PT_BLOCK) void k_to_u8(const double *__restrict__ rgb, long n,
+                                                    const unsigned long long *__restrict__ keys,
+                                                    unsigned char *__restrict__ out) {
+    const long i = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double coef = f64_unkey(keys[i % 3]);
+    double v = rgb[i];
+    if (!(coef == 0.)) v = (255. * v) / coef;
+    int q = 0;
+    if (v > -2147483649. && v < 2147483648.) q = (int)v;
+    out[i] = (unsigned char)(q & 255);
+}
+
+hipError_t pt_launch_film_to_u8(hipStream_t stream, const double *rgb, long npix, unsigned long long *keys,
+                                unsigned char *out) {
+    if (npix <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(keys, 0, 3 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    long g = (npix + PT_BLOCK - 1) / PT_BLOCK;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_chan_max, dim3((int)g), dim3(PT_BLOCK), 0, stream, rgb, npix, keys);
+    const long n = 3 * npix;
+    hipLaunchKernelGGL(k_to_u8, dim3((int)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, stream, rgb, n, keys, out);
+    return hipGetLastError();
+}

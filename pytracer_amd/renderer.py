@@ -18,6 +18,7 @@ import numpy as np
 
 from . import _abi as A
 from . import flatten as F
+from . import imageio as IO
 
 
 def shard_tile(sampler, rank, world, mode='samples'):
@@ -87,10 +88,29 @@ class GpuSamplerRenderer(object):
     """Sample-driven renderer on the GPU; constructor signature of SamplerRenderer (renderer.py:52-56)."""
 
     def __init__(self, s, c, si, vi=None, device=None, seed=0, sampler_mode='device', pretest=False,
-                 shard_mode='samples', write_image=True):
+                 shard_mode='samples', write_image=True, image='film', checkpoint=None, checkpoint_every=None,
+                 crop_update='reference', on_piece=None):
+        """Beyond the reference's (s, c, si, vi):
+
+        image: how rank 0 produces the picture when `write_image` is true.
+          'film' — fill ``camera.film.pixels`` and call the film object's own ``write_image()``, i.e. the
+                   reference's per-pixel Python loop (film/film.py:237-260): slow, but any Film subclass works;
+          'gpu'  — resolve and tone-map on the GPU (pt_film_resolve, pt_film_to_u8) and save the PNG to
+                   ``film.filename`` directly (pytracer_amd.imageio); ``film.pixels`` is still filled.
+        checkpoint / checkpoint_every: path of an accumulator checkpoint and the number of sample indices
+          per piece.  The tile is rendered piece by piece; after each piece the accumulators are saved
+          (and, with image='gpu', the picture so far is written: progressive output).  A later render of
+          the same scene/camera/sampler/integrator/seed finds the file and continues after the last
+          finished piece; a checkpoint of anything else is ignored.  Ranks keep separate files
+          (``<path>.rank<k>`` for world > 1).  The file is removed when the render completes.
+          With image='gpu' the picture shows THIS render's accumulators; what an earlier render left in
+          ``film.pixels`` is added to the pixels (like add_sample would) but only image='film' paints it.
+        on_piece: callable(s_done, s_total) after every finished piece (progress reporting)."""
         if vi is not None:
             raise NotImplementedError('volume integrators are outside the supported hot path '
                                       '(the reference ships none: integrator/volume is empty)')
+        if image not in ('film', 'gpu'):
+            raise ValueError("image must be 'film' or 'gpu'")
         self.sampler = s
         self.camera = c
         self.surf_integrator = si
@@ -101,7 +121,14 @@ class GpuSamplerRenderer(object):
         self.pretest = pretest
         self.shard_mode = shard_mode
         self.write_image = write_image
+        self.image = image
+        self.checkpoint = checkpoint
+        self.checkpoint_every = checkpoint_every
+        self.crop_update = crop_update
+        self.on_piece = on_piece
         self.stats = None
+        self.image8 = None                    # the last 8-bit picture (image='gpu'), numpy [y, x, 3]
+        self.resumed_from = None              # sample index a checkpoint let this render start from
         self._ctx = None
 
     # -- the part of the reference API that still makes sense on a batch machine -------------
@@ -143,16 +170,44 @@ class GpuSamplerRenderer(object):
             table = torch.from_numpy(t).to(dev)
         acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device=dev)
         self.stats = A.pt_stats()
+        ckpt, start = None, None
+        self.resumed_from = None
+        if self.checkpoint:
+            path = self.checkpoint if world == 1 else '%s.rank%d' % (self.checkpoint, rank)
+            ckpt = IO.Checkpoint(path, IO.render_key(flat, cam, film, smp, integ, tile, self.sampler_mode))
+            found = ckpt.load(tuple(acc.shape))
+            if found is not None:
+                acc.copy_(torch.from_numpy(found[0]))
+                start = self.resumed_from = found[1]
+        progressive = ckpt is not None and self.write_image and self.image == 'gpu' and world == 1
         with torch.cuda.device(dev):
-            ctx.render(cam, film, smp, integ, tile, acc, table=table, stats=self.stats)
+            for piece in IO.sample_chunks(tile, self.checkpoint_every if ckpt else None, start):
+                ctx.render(cam, film, smp, integ, piece, acc, table=table, stats=self.stats)
+                if ckpt is not None and piece.s1 < tile.s1:
+                    torch.cuda.synchronize()
+                    ckpt.save(acc.cpu().numpy(), piece.s1)
+                    if progressive:
+                        self._write_gpu_image(ctx, film_obj, acc)
+                if self.on_piece is not None:
+                    self.on_piece(piece.s1 - tile.s0, tile.s1 - tile.s0)
             if dist is not None and world > 1:
                 dist.reduce(acc, dst=0)        # the only collective: sum of film accumulators
             torch.cuda.synchronize()
-        if rank == 0:
-            write_film(film_obj, acc.cpu().numpy())
-            if self.write_image:
-                film_obj.write_image()
+            if rank == 0:
+                write_film(film_obj, acc.cpu().numpy())
+                if self.write_image:
+                    if self.image == 'gpu':
+                        self._write_gpu_image(ctx, film_obj, acc)
+                    else:
+                        film_obj.write_image()
+        if ckpt is not None:
+            ckpt.remove()
         return None                            # SamplerRenderer.render returns None (renderer.py:84-111)
+
+    def _write_gpu_image(self, ctx, film_obj, acc):
+        """ImageFilm.write_image (film/film.py:237-260) with both array passes on the device."""
+        rgb8 = ctx.film_to_u8(ctx.film_resolve(acc)).cpu().numpy()
+        self.image8 = IO.write_film_image(film_obj, rgb8, update=self.crop_update)
 
 
 def write_film(film_obj, acc):

@@ -39,6 +39,7 @@ def lib():
                                  C.POINTER(A.pt_sampler_desc), C.POINTER(A.pt_integrator_desc), C.POINTER(A.pt_tile),
                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(A.pt_stats)]
         L.pto_film_resolve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.pto_film_to_u8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.pto_camera_rays.argtypes = [C.POINTER(A.pt_camera), C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
         L.pto_hit_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
                                        C.c_void_p]
@@ -114,3 +115,10 @@ def film_resolve(acc):
     rgb = np.empty(acc.shape[:2] + (3,))
     lib().pto_film_resolve(acc.ctypes.data, acc.shape[1], acc.shape[0], rgb.ctypes.data)
     return rgb
+
+
+def film_to_u8(rgb):
+    rgb = np.ascontiguousarray(rgb, np.float64)
+    out = np.empty(rgb.shape, np.uint8)
+    lib().pto_film_to_u8(rgb.ctypes.data, rgb.shape[1], rgb.shape[0], out.ctypes.data)
+    return out

@@ -20,7 +20,7 @@ HEADER = os.path.join(ROOT, 'include', 'pytracer_hip.h')
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(pt_[a-z_]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(pt_[a-z0-9_]+)\s*\(', src)))
 
 
 def test_header_symbols_exported():
