@@ -726,6 +726,40 @@ def gen_xtra():
 
 ALL = dict(xtra=gen_xtra, loop=gen_loop, specmini=gen_specmini, c2=gen_c2, c4mini=gen_c4mini, scene=gen_scene, direct=gen_direct, path=gen_path, c1=gen_c1_window, bvh=gen_bvh)
 
+def gen_converged():
+    """The reference, untouched (its own StratifiedSampler, np.random streams and SamplerRenderer.render), on a
+    24x24-pixel window of the 128x128 head mesh at 8x8 = 64 spp: the image the production (in-kernel) sample
+    streams must converge to.  CONV_KIND=direct|path picks the integrator (run both, in parallel if you like)."""
+    import contextlib
+    import io
+    import examples.head_mesh as model
+    kind = os.environ.get('CONV_KIND', 'direct')
+    sub = (52, 76, 44, 68)
+    camera = model.configure_camera(x_res=128, y_res=128, file_name='/tmp/_fixture_conv_%s.png' % kind)
+    sampler = StratifiedSampler(sub[0], sub[1], sub[2], sub[3], 8, 8, True, 0., 0.)
+    integ = DirectLightingIntegrator() if kind == 'direct' else PathIntegrator(max_depth=5)
+    renderer = SamplerRenderer(sampler, camera, integ, None)
+    np.random.seed(1234 if kind == 'direct' else 4321)
+    t = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        renderer.render(model.scene)
+    dt = time.time() - t
+    film = camera.film
+    W, H = film.xPixel_cnt, film.yPixel_cnt
+    Lxyz = np.zeros((H, W, 3))
+    wsum = np.zeros((H, W))
+    for x in range(W):
+        for y in range(H):
+            Lxyz[y, x] = film.pixels[x][y].Lxyz
+            wsum[y, x] = film.pixels[x][y].weight_sum
+    np.savez_compressed(os.path.join(OUT, 'converged_%s_24x24x64.npz' % kind), film_Lxyz=Lxyz, film_wsum=wsum,
+                        sub=np.array(sub, np.int32), spp=np.array([8, 8], np.int32), seconds=np.float64(dt))
+    print('converged %s: %.1fs, sum Lxyz %.6f' % (kind, dt, Lxyz.sum()))
+
+
+ALL['converged'] = gen_converged
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)
     for w in which:
