@@ -332,7 +332,12 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     DScene &s = c->sc;
     s.nodes = (const GNode *)c->d_nodes;
     s.top = n_top ? (const TopNode *)c->d_top : nullptr;
-    s.n_top = n_top; s._pad0 = 0;
+    s.n_top = n_top;
+    s.exact_slab = 0;
+    for (size_t i = 0; i < (size_t)d->n_nodes && !s.exact_slab; i++) {
+        const double *b = d->node_bounds + 6 * i;
+        if (!(b[0] <= b[3]) || !(b[1] <= b[4]) || !(b[2] <= b[5])) s.exact_slab = 1;
+    }
     s.tris = (const GTri *)c->d_tris;
     s.tri_verts = (const double *)c->d_verts;
     s.tri_mat = (const int32_t *)c->d_mat;

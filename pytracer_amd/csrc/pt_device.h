@@ -99,7 +99,8 @@ struct __attribute__((aligned(16))) TopNode {   // 64 B
 struct DScene {
     const GNode *nodes;
     const TopNode *top;        // the first n_top nodes in breadth-first order, or nullptr
-    int32_t n_top, _pad0;
+    int32_t n_top;
+    int32_t exact_slab;        // a node box with min > max (or NaN): only the reference's own comparison order is exact
     const GTri *tris;
     const double *tri_verts;   // [n_tris][9] p1,p2,p3 for shading geometry
     const int32_t *tri_mat;

@@ -34,66 +34,107 @@ __device__ __forceinline__ bool tri_test(const GTri *tp, const Ray &r, double &t
     const double2 *q = reinterpret_cast<const double2 *>(tp);
     return tri_math(q[0], q[1], q[2], q[3], q[4], r, t_out, b1_out, b2_out);
 }
+// BVH._intersect_p (bvh.py:295-320): the slab test of a node box in the reference's comparison order.
+// PT_FAST_SLAB: when every 1/d is finite and the box is ordered (min <= max), each axis' two plane distances are
+// ordered by the monotonicity of rounding, none is NaN, and the reference's nested tests reduce to
+//   max(near_x, near_y, near_z) <= min(far_x, far_y, far_z)  and  near < maxt  and  far > mint
+// with near/far = min/max of the axis' two products: the same six subtractions and products, so the same decision
+// bit for bit, without the sign selects and the nested branches.  Rays with a zero (or subnormal, or NaN)
+// direction component — where 0 x inf = NaN makes the reference's outcome depend on its comparison order — and
+// scenes with unordered boxes keep the literal form.
+#ifndef PT_FAST_SLAB
+#define PT_FAST_SLAB 1
+#endif
+struct SlabRay {
+    double invx, invy, invz;
+    bool negx, negy, negz, fast;
+    int negmask;               // bit a = direction component a is negative
+};
+__device__ __forceinline__ SlabRay slab_ray(const DScene &sc, const Ray &r) {
+    SlabRay v;
+    v.invx = 1.0 / r.d.x; v.invy = 1.0 / r.d.y; v.invz = 1.0 / r.d.z;
+    v.negx = r.d.x < 0.0; v.negy = r.d.y < 0.0; v.negz = r.d.z < 0.0;
+    v.negmask = (v.negx ? 1 : 0) | (v.negy ? 2 : 0) | (v.negz ? 4 : 0);
+    v.fast = PT_FAST_SLAB && !sc.exact_slab && isfinite(v.invx) && isfinite(v.invy) && isfinite(v.invz);
+    return v;
+}
+template <bool FAST>
+__device__ __forceinline__ bool slab_hit(const double2 n0, const double2 n1, const double2 n2, const Ray &r,
+                                         const SlabRay &v) {
+    // n0 = bmin.xy, n1 = bmin.z bmax.x, n2 = bmax.yz
+    if (FAST) {
+        const double x0 = (n0.x - r.o.x) * v.invx, x1 = (n1.y - r.o.x) * v.invx;
+        const double y0 = (n0.y - r.o.y) * v.invy, y1 = (n2.x - r.o.y) * v.invy;
+        const double z0 = (n1.x - r.o.z) * v.invz, z1 = (n2.y - r.o.z) * v.invz;
+        const double tnear = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+        const double tfar = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+        return (tnear <= tfar) && (tnear < r.maxt) && (tfar > r.mint);
+    }
+    double tmin = ((v.negx ? n1.y : n0.x) - r.o.x) * v.invx;
+    double tmax = ((v.negx ? n0.x : n1.y) - r.o.x) * v.invx;
+    const double tmin_y = ((v.negy ? n2.x : n0.y) - r.o.y) * v.invy;
+    const double tmax_y = ((v.negy ? n0.y : n2.x) - r.o.y) * v.invy;
+    if (tmin > tmax_y || tmin_y > tmax) return false;
+    if (tmin_y > tmin) tmin = tmin_y;
+    if (tmax_y < tmax) tmax = tmax_y;
+    const double tmin_z = ((v.negz ? n2.y : n1.x) - r.o.z) * v.invz;
+    const double tmax_z = ((v.negz ? n1.x : n2.y) - r.o.z) * v.invz;
+    if (tmin > tmax_z || tmin_z > tmax) return false;
+    if (tmin_z > tmin) tmin = tmin_z;
+    if (tmax_z < tmax) tmax = tmax_z;
+    return (tmin < r.maxt) && (tmax > r.mint);
+}
+
 // BVH.intersect (bvh.py:322-365) / BVH.intersect_p (:367-410) with BVH._intersect_p (:295-320).
 // Returns the primitive index (closest; -1 = miss) or 0/1 (any hit).  r.maxt is shrunk by
 // every accepted closest hit (aggregate/primitive.py:107).
-template <bool ANY>
-__device__ __forceinline__ int traverse(const DScene &sc, Ray &r, int *stack, double &b1o, double &b2o,
-                                        unsigned &nvis, unsigned &ntri) {
+template <bool ANY, bool FAST>
+__device__ __forceinline__ int traverse_loop(const DScene &sc, Ray &r, const SlabRay &sv, int *stack, double &b1o,
+                                             double &b2o, unsigned &nvis, unsigned &ntri) {
     int result = ANY ? 0 : -1;
-    if (sc.n_nodes == 0) return result;
-    const double invx = 1.0 / r.d.x, invy = 1.0 / r.d.y, invz = 1.0 / r.d.z;
-    const bool negx = r.d.x < 0.0, negy = r.d.y < 0.0, negz = r.d.z < 0.0;
     int todo_idx = 0, node_idx = 0;
     for (;;) {
         const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node_idx);
         const double2 n0 = q[0], n1 = q[1], n2 = q[2];   // bmin.xy | bmin.z bmax.x | bmax.yz
         const int2 meta = *reinterpret_cast<const int2 *>(&q[3]);
         nvis++;
-        double tmin = ((negx ? n1.y : n0.x) - r.o.x) * invx;
-        double tmax = ((negx ? n0.x : n1.y) - r.o.x) * invx;
-        double tmin_y = ((negy ? n2.x : n0.y) - r.o.y) * invy;
-        double tmax_y = ((negy ? n0.y : n2.x) - r.o.y) * invy;
-        bool hitbox = !(tmin > tmax_y || tmin_y > tmax);
-        if (hitbox) {
-            if (tmin_y > tmin) tmin = tmin_y;
-            if (tmax_y < tmax) tmax = tmax_y;
-            double tmin_z = ((negz ? n2.y : n1.x) - r.o.z) * invz;
-            double tmax_z = ((negz ? n1.x : n2.y) - r.o.z) * invz;
-            hitbox = !(tmin > tmax_z || tmin_z > tmax);
-            if (hitbox) {
-                if (tmin_z > tmin) tmin = tmin_z;
-                if (tmax_z < tmax) tmax = tmax_z;
-                hitbox = (tmin < r.maxt) && (tmax > r.mint);
-            }
-        }
-        if (hitbox) {
-            const int nprim = meta.y & 0xFFFF;
-            if (nprim > 0) {
-                for (int i = 0; i < nprim; i++) {
-                    double t, b1, b2;
-                    ntri++;
-                    if (tri_test(sc.tris + meta.x + i, r, t, b1, b2)) {
-                        if (ANY) return 1;
-                        result = meta.x + i;
-                        b1o = b1; b2o = b2;
-                        r.maxt = t;
-                    }
+        const bool hitbox = slab_hit<FAST>(n0, n1, n2, r, sv);
+        const int nprim = meta.y & 0xFFFF;
+        if (hitbox && nprim > 0) {
+            for (int i = 0; i < nprim; i++) {
+                double t, b1, b2;
+                ntri++;
+                if (tri_test(sc.tris + meta.x + i, r, t, b1, b2)) {
+                    if (ANY) return 1;
+                    result = meta.x + i;
+                    b1o = b1; b2o = b2;
+                    r.maxt = t;
                 }
-                if (todo_idx == 0) break;
-                node_idx = stack[(--todo_idx) * PT_BLOCK];
-            } else {
-                const int axis = meta.y >> 16;
-                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-                stack[(todo_idx++) * PT_BLOCK] = neg ? node_idx + 1 : meta.x;
-                node_idx = neg ? meta.x : node_idx + 1;
             }
-        } else {
-            if (todo_idx == 0) break;
-            node_idx = stack[(--todo_idx) * PT_BLOCK];
         }
+        // next node: one straight line for descending and popping lanes (an if/else here makes the compiler nest
+        // a descend-only loop inside the walk and park the popping lanes: closest hit 44 -> 63 ms)
+        const bool inner = hitbox && nprim == 0;
+        const bool neg = (sv.negmask >> (meta.y >> 16)) & 1;          // dir_is_neg[node.axis], bvh.py:350
+        const int next = node_idx + 1;
+        if (!inner && todo_idx == 0) break;
+        int *slot = stack + (inner ? todo_idx : todo_idx - 1) * PT_BLOCK;
+        if (inner) *slot = neg ? next : meta.x;
+        const int popped = *slot;
+        node_idx = inner ? (neg ? meta.x : next) : popped;
+        todo_idx += inner ? 1 : -1;
     }
     return result;
+}
+// The two forms of the slab test are two loops (not a branch per visit): the literal one runs for the rare lanes
+// that need it after the others are done.
+template <bool ANY>
+__device__ __forceinline__ int traverse(const DScene &sc, Ray &r, int *stack, double &b1o, double &b2o,
+                                        unsigned &nvis, unsigned &ntri) {
+    if (sc.n_nodes == 0) return ANY ? 0 : -1;
+    const SlabRay sv = slab_ray(sc, r);
+    if (sv.fast) return traverse_loop<ANY, true>(sc, r, sv, stack, b1o, b2o, nvis, ntri);
+    return traverse_loop<ANY, false>(sc, r, sv, stack, b1o, b2o, nvis, ntri);
 }
 
 // Census counters are sharded ([PT_CNT_SHARDS][CNT_COUNT], summed on the host): thousands of
@@ -121,7 +162,7 @@ __device__ __forceinline__ void trace_count(unsigned long long *counters, unsign
 // the shadow "resolve" (K6) is fused: an unoccluded ray adds its precomputed contribution to
 // L[slot].
 #ifndef PT_TRACE_WAVES
-#define PT_TRACE_WAVES 6   // <= 80 VGPRs: 6 waves/SIMD, the same residency the 24-entry LDS stack allows
+#define PT_TRACE_WAVES 5   // <= 96 VGPRs: the two loops of traverse<> spill at 80 (6 waves/SIMD measured slower)
 #endif
 template <bool ANY>
 __device__ __forceinline__ void trace_one(const DScene &sc, const double *__restrict__ rays, long stride, long i,
@@ -196,13 +237,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, c
 // comparison and every counter are those of traverse<>.
 #define PT_TOP_BLOCK 1024
 
-template <bool ANY>
-__device__ __forceinline__ int traverse_top(const DScene &sc, const TopNode *top, Ray &r, int *stack, double &b1o,
-                                            double &b2o, unsigned &nvis, unsigned &ntri) {
+template <bool ANY, bool FAST>
+__device__ __forceinline__ int traverse_top_loop(const DScene &sc, const TopNode *top, Ray &r, const SlabRay &sv,
+                                                 int *stack, double &b1o, double &b2o, unsigned &nvis, unsigned &ntri) {
     int result = ANY ? 0 : -1;
-    if (sc.n_nodes == 0) return result;
-    const double invx = 1.0 / r.d.x, invy = 1.0 / r.d.y, invz = 1.0 / r.d.z;
-    const bool negx = r.d.x < 0.0, negy = r.d.y < 0.0, negz = r.d.z < 0.0;
     int todo_idx = 0, ref = ~0;   // the root is slot 0
     for (;;) {
         double2 n0, n1, n2;
@@ -219,50 +257,38 @@ __device__ __forceinline__ int traverse_top(const DScene &sc, const TopNode *top
             offset = m.x; nprim_axis = m.y; ref0 = ref + 1; ref1 = m.x;
         }
         nvis++;
-        double tmin = ((negx ? n1.y : n0.x) - r.o.x) * invx;
-        double tmax = ((negx ? n0.x : n1.y) - r.o.x) * invx;
-        double tmin_y = ((negy ? n2.x : n0.y) - r.o.y) * invy;
-        double tmax_y = ((negy ? n0.y : n2.x) - r.o.y) * invy;
-        bool hitbox = !(tmin > tmax_y || tmin_y > tmax);
-        if (hitbox) {
-            if (tmin_y > tmin) tmin = tmin_y;
-            if (tmax_y < tmax) tmax = tmax_y;
-            double tmin_z = ((negz ? n2.y : n1.x) - r.o.z) * invz;
-            double tmax_z = ((negz ? n1.x : n2.y) - r.o.z) * invz;
-            hitbox = !(tmin > tmax_z || tmin_z > tmax);
-            if (hitbox) {
-                if (tmin_z > tmin) tmin = tmin_z;
-                if (tmax_z < tmax) tmax = tmax_z;
-                hitbox = (tmin < r.maxt) && (tmax > r.mint);
-            }
-        }
-        if (hitbox) {
-            const int nprim = nprim_axis & 0xFFFF;
-            if (nprim > 0) {
-                for (int i = 0; i < nprim; i++) {
-                    double t, b1, b2;
-                    ntri++;
-                    if (tri_test(sc.tris + offset + i, r, t, b1, b2)) {
-                        if (ANY) return 1;
-                        result = offset + i;
-                        b1o = b1; b2o = b2;
-                        r.maxt = t;
-                    }
+        const bool hitbox = slab_hit<FAST>(n0, n1, n2, r, sv);
+        const int nprim = nprim_axis & 0xFFFF;
+        if (hitbox && nprim > 0) {
+            for (int i = 0; i < nprim; i++) {
+                double t, b1, b2;
+                ntri++;
+                if (tri_test(sc.tris + offset + i, r, t, b1, b2)) {
+                    if (ANY) return 1;
+                    result = offset + i;
+                    b1o = b1; b2o = b2;
+                    r.maxt = t;
                 }
-                if (todo_idx == 0) break;
-                ref = stack[(--todo_idx) * PT_TOP_BLOCK];
-            } else {
-                const int axis = nprim_axis >> 16;
-                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-                stack[(todo_idx++) * PT_TOP_BLOCK] = neg ? ref0 : ref1;
-                ref = neg ? ref1 : ref0;
             }
-        } else {
-            if (todo_idx == 0) break;
-            ref = stack[(--todo_idx) * PT_TOP_BLOCK];
         }
+        const bool inner = hitbox && nprim == 0;                      // straight line, as in traverse_loop
+        const bool neg = (sv.negmask >> (nprim_axis >> 16)) & 1;
+        if (!inner && todo_idx == 0) break;
+        int *slot = stack + (inner ? todo_idx : todo_idx - 1) * PT_TOP_BLOCK;
+        if (inner) *slot = neg ? ref0 : ref1;
+        const int popped = *slot;
+        ref = inner ? (neg ? ref1 : ref0) : popped;
+        todo_idx += inner ? 1 : -1;
     }
     return result;
+}
+template <bool ANY>
+__device__ __forceinline__ int traverse_top(const DScene &sc, const TopNode *top, Ray &r, int *stack, double &b1o,
+                                            double &b2o, unsigned &nvis, unsigned &ntri) {
+    if (sc.n_nodes == 0) return ANY ? 0 : -1;
+    const SlabRay sv = slab_ray(sc, r);
+    if (sv.fast) return traverse_top_loop<ANY, true>(sc, top, r, sv, stack, b1o, b2o, nvis, ntri);
+    return traverse_top_loop<ANY, false>(sc, top, r, sv, stack, b1o, b2o, nvis, ntri);
 }
 
 template <bool ANY>

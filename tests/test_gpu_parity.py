@@ -104,6 +104,39 @@ def test_intersect_soups(torch_cuda, ctx, golden_dir, name):
     assert np.array_equal(gp, op) and np.array_equal(gt, ot)
 
 
+def test_axis_parallel_rays_on_box_planes(torch_cuda, ctx, golden_dir):
+    """Rays with zero and -0.0 direction components whose origins lie exactly on node box planes (NaN slab
+    distances, inv = -inf with dir_is_neg false): the fast slab test must not be used for them — results equal
+    the REFERENCE's, outputs and the node/triangle census are bitwise the oracle's."""
+    import oracle_lib as O
+    d = load(golden_dir, 'bvh_axis_rays.npz')
+    flat = pa.flat_scene_from_npz(d)
+    ctx.upload(flat)
+    osc = O.OracleScene(flat)
+    rays = np.ascontiguousarray(d['rays'].T)
+    for any_hit in (False, True):
+        gs, os_ = A.pt_stats(), A.pt_stats()
+        gp, gt, gb1, gb2 = gpu_intersect(torch_cuda, ctx, rays, any_hit, stats=gs)
+        op, ot, ob1, ob2 = osc.intersect(rays, any_hit=any_hit, stats=os_)
+        assert np.array_equal(gp, op)
+        assert (gs.node_visits, gs.tri_tests) == (os_.node_visits, os_.tri_tests)
+        if any_hit:
+            assert np.array_equal(gp, d['res'][:, 3].astype(np.int32))
+        else:
+            assert np.array_equal(gt, ot) and np.array_equal(gb1, ob1) and np.array_equal(gb2, ob2)
+            assert np.array_equal(gp, d['res'][:, 1].astype(np.int32))
+            hit = gp >= 0
+            np.testing.assert_allclose(gt[hit], d['res'][hit, 2], rtol=1e-12)
+    # the same rays nudged off the planes and off zero take the fast form: still the oracle's, census included
+    r2 = rays.copy()
+    r2[3:6] += 1e-9
+    gs, os_ = A.pt_stats(), A.pt_stats()
+    gp, gt, _, _ = gpu_intersect(torch_cuda, ctx, r2, False, stats=gs)
+    op, ot, _, _ = osc.intersect(r2, any_hit=False, stats=os_)
+    assert np.array_equal(gp, op) and np.array_equal(gt, ot)
+    assert (gs.node_visits, gs.tri_tests) == (os_.node_visits, os_.tri_tests)
+
+
 def test_top_of_tree_kernel_is_bitwise_the_same(torch_cuda, golden_dir, head):
     """k_trace_top (first breadth-first nodes staged in LDS, PT_TRACE_TOP=1; off by default because it
     measured slower) walks the same nodes in the same order: outputs and visit counts equal the oracle's."""

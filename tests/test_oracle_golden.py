@@ -171,3 +171,18 @@ def test_pretest_flag_does_not_change_image(golden_dir, head):
     a1, L1, s1 = render_fixture(osc, d, pa.integrator_desc(A.PT_INTEG_DIRECT, 5, pretest=True))
     assert np.array_equal(L0, L1) and np.array_equal(a0, a1)
     assert s1.rays_any == s0.rays_any + s0.camera_samples
+
+
+def test_axis_parallel_rays_on_box_planes(golden_dir):
+    """The oracle's literal slab test (comparison order of bvh.py:295-320) on the rays where that order decides:
+    zero / -0.0 direction components, origins exactly on node box planes (tools/oracle/gen_fixtures.py `axis`)."""
+    d = load(golden_dir, 'bvh_axis_rays.npz')
+    osc = O.OracleScene(pa.flat_scene_from_npz(d))
+    rays = np.ascontiguousarray(d['rays'].T)
+    prim, t, _, _ = osc.intersect(rays, any_hit=False)
+    assert np.array_equal(prim, d['res'][:, 1].astype(np.int32))
+    hit = prim >= 0
+    assert hit.sum() > 100
+    np.testing.assert_allclose(t[hit], d['res'][hit, 2], rtol=1e-12)     # np.dot (BLAS) vs plain sums: last ulps
+    anyh, _, _, _ = osc.intersect(rays, any_hit=True)
+    assert np.array_equal(anyh, d['res'][:, 3].astype(np.int32))

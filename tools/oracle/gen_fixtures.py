@@ -760,6 +760,67 @@ def gen_converged():
 ALL['converged'] = gen_converged
 
 
+def gen_axis():
+    """Axis-parallel rays through the soup2000 tree whose origins lie EXACTLY on node box planes: 1/d = +-inf and
+    (plane - origin) = 0 give NaN slab distances, and a -0.0 direction component gives inv = -inf with
+    dir_is_neg false — the cases where the outcome depends on the literal comparison order of
+    BVH._intersect_p (bvh.py:295-320)."""
+    from pytracer.shape import create_triangle_mesh
+    from pytracer.transform import Transform
+    from pytracer.material import MatteMaterial
+    from pytracer.texture import ConstantTexture
+    from pytracer.scene import Scene
+    P, idx = soup(2000, 12, 0)
+    tr = Transform.translate(geo.Vector(0., 0., 0.))
+    mesh = create_triangle_mesh(tr, tr.inverse(), False, {'indices': list(idx), 'P': list(P.ravel())})
+    mat = MatteMaterial(ConstantTexture(Spectrum([.5, .5, .5])), ConstantTexture(0.))
+    bvh = BVH([GeometricPrimitive(mesh, mat)])
+    d = dump_scene(Scene(bvh, [], None))
+    nb = d['node_bounds']
+    inner = [i for i in range(96) if d['node_meta'][i, 1] == 0]
+    rng = np.random.default_rng(77)
+    rows = []
+    for k in range(720):
+        # an interior node near the root: certainly visited, and its box corners are made of coordinates of
+        # different triangles (a leaf's corner can be a vertex: a ray through it is a last-ulp coin toss between
+        # BLAS ddot and any restatement, which is not what this fixture is about)
+        node = nb[inner[rng.integers(0, len(inner))]]
+        axis = k % 3                                       # the ray runs along this axis
+        sign = 1. if (k // 3) % 2 == 0 else -1.
+        o = rng.uniform(node[0:3], node[3:6])              # inside the node's box ...
+        o[axis] = node[axis] - 3. if sign > 0 else node[3 + axis] + 3.     # ... seen from outside along the axis
+        dvec = np.zeros(3)
+        dvec[axis] = sign
+        mode = (k // 6) % 6
+        a1, a2 = (axis + 1) % 3, (axis + 2) % 3
+        if mode in (1, 3, 5):
+            o[a1] = node[a1 + (3 if rng.uniform() < .5 else 0)]           # on a plane of the box: 0 * inf
+        if mode in (2, 3):
+            o[a2] = node[a2 + (3 if rng.uniform() < .5 else 0)]
+        if mode in (4, 5):
+            dvec[a1] = -0.0                                                # inv = -inf, dir_is_neg = False
+        if mode == 5:
+            dvec[a2] = -0.0
+        rows.append(np.concatenate([o, dvec, [0., np.inf if k % 5 else 25.]]))
+    rays = np.array(rows)
+    prim_index = {id(p): i for i, p in enumerate(bvh.primitives)}
+    res = np.zeros((len(rays), 4))
+    for i in range(len(rays)):
+        r = geo.Ray(geo.Point(*rays[i, 0:3]), geo.Vector(*rays[i, 3:6]), rays[i, 6], rays[i, 7])
+        isect = Intersection()
+        hit = bvh.intersect(r, isect)
+        r2 = geo.Ray(geo.Point(*rays[i, 0:3]), geo.Vector(*rays[i, 3:6]), rays[i, 6], rays[i, 7])
+        anyh = bvh.intersect_p(r2)
+        res[i] = (int(hit), prim_index[id(isect.primitive)] if hit else -1, r.maxt, int(anyh))
+    d['rays'] = rays
+    d['res'] = res
+    np.savez_compressed(os.path.join(OUT, 'bvh_axis_rays.npz'), **d)
+    print('axis rays: nodes %d hits %d any %d' % (len(bvh.nodes), int(res[:, 0].sum()), int(res[:, 3].sum())))
+
+
+ALL['axis'] = gen_axis
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)
     for w in which:
