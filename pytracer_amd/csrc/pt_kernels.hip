@@ -126,6 +126,7 @@ __device__ __forceinline__ int traverse_loop(const DScene &sc, Ray &r, const Sla
     }
     return result;
 }
+
 // The two forms of the slab test are two loops (not a branch per visit): the literal one runs for the rare lanes
 // that need it after the others are done.
 template <bool ANY>
@@ -161,6 +162,9 @@ __device__ __forceinline__ void trace_count(unsigned long long *counters, unsign
 // rays: component-major SoA [8][stride]; outputs per ray at the ray's own index.  ANY + rs.L:
 // the shadow "resolve" (K6) is fused: an unoccluded ray adds its precomputed contribution to
 // L[slot].
+#ifndef PT_REFILL
+#define PT_REFILL 0     // lanes that must be free before the wave fetches new rays (0: no refill)
+#endif
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 5   // <= 96 VGPRs: the two loops of traverse<> spill at 80 (6 waves/SIMD measured slower)
 #endif
@@ -213,11 +217,99 @@ __global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, c
         if (sub < nsub) {
             const int n = seg_counts[r * PT_CNT_STRIDE];
             const long first = (long)r * seg;
+#if PT_REFILL
+            // Lane refill: the wave owns the 64-ray chunks sub, sub + nsub, ... of its region, numbered m = 0..M-1
+            // ray by ray; a lane whose ray is finished takes the wave's next unclaimed ray once PT_REFILL lanes are
+            // free (ballot + prefix count, no atomics), and every iteration is ONE node visit for all busy lanes.
+            const int stride64 = nsub * 64, base0 = sub * 64;
+            int M = 0;
+            if (base0 < n) {
+                const int nch = (n - base0 + stride64 - 1) / stride64;
+                const int last = n - (base0 + (nch - 1) * stride64);
+                M = (nch - 1) * 64 + (last < 64 ? last : 64);
+            }
+            int *stack = s_stack + threadIdx.x;
+            int m_next = 0;
+            bool busy = false;
+            Ray ry;
+            SlabRay sv;
+            long ri = 0;
+            int node_idx = 0, todo_idx = 0, result = 0;
+            double hb1 = 0., hb2 = 0.;
+            for (;;) {
+                const unsigned long long freem = __ballot(!busy);
+                const int nfree = __popcll(freem);
+                if (m_next < M && (nfree >= PT_REFILL || nfree == 64)) {
+                    if (!busy) {
+                        const int m = m_next + (int)__mbcnt_hi((unsigned)(freem >> 32), __mbcnt_lo((unsigned)freem, 0u));
+                        if (m < M) {
+                            ri = first + (long)(m >> 6) * stride64 + base0 + (m & 63);
+                            ry.o = mk3(rays[ri], rays[stride + ri], rays[2 * stride + ri]);
+                            ry.d = mk3(rays[3 * stride + ri], rays[4 * stride + ri], rays[5 * stride + ri]);
+                            ry.mint = rays[6 * stride + ri];
+                            ry.maxt = rays[7 * stride + ri];
+                            sv = slab_ray(sc, ry);
+                            node_idx = 0; todo_idx = 0; result = ANY ? 0 : -1; hb1 = 0.; hb2 = 0.;
+                            busy = true;
+                            nray++;
+                        }
+                    }
+                    m_next += nfree;
+                }
+                if (__ballot(busy) == 0ull) break;
+                if (busy) {
+                    const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node_idx);
+                    const double2 n0 = q[0], n1 = q[1], n2 = q[2];
+                    const int2 meta = *reinterpret_cast<const int2 *>(&q[3]);
+                    nvis++;
+                    const bool hitbox = sv.fast ? slab_hit<true>(n0, n1, n2, ry, sv) : slab_hit<false>(n0, n1, n2, ry, sv);
+                    const int nprim = meta.y & 0xFFFF;
+                    bool fin = false;
+                    if (hitbox && nprim > 0) {
+                        for (int i = 0; i < nprim; i++) {
+                            double t, b1, b2;
+                            ntri++;
+                            if (tri_test(sc.tris + meta.x + i, ry, t, b1, b2)) {
+                                if (ANY) { result = 1; fin = true; break; }
+                                result = meta.x + i;
+                                hb1 = b1; hb2 = b2;
+                                ry.maxt = t;
+                            }
+                        }
+                    }
+                    const bool inner = hitbox && nprim == 0;
+                    const bool neg = (sv.negmask >> (meta.y >> 16)) & 1;
+                    const int next = node_idx + 1;
+                    if (!inner && todo_idx == 0) fin = true;
+                    if (!fin) {
+                        int *slot = stack + (inner ? todo_idx : todo_idx - 1) * PT_BLOCK;
+                        if (inner) *slot = neg ? next : meta.x;
+                        const int popped = *slot;
+                        node_idx = inner ? (neg ? meta.x : next) : popped;
+                        todo_idx += inner ? 1 : -1;
+                    } else {
+                        if (out_prim) out_prim[ri] = result;
+                        if (!ANY) {
+                            if (out_t) out_t[ri] = ry.maxt;
+                            if (out_b1) out_b1[ri] = hb1;
+                            if (out_b2) out_b2[ri] = hb2;
+                        } else if (rs.L && result == 0) {
+                            const int slot = rs.slot[ri];
+                            unsafeAtomicAdd(rs.L + slot, rs.c[ri]);
+                            unsafeAtomicAdd(rs.L + rs.lstride + slot, rs.c[rs.cstride + ri]);
+                            unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + ri]);
+                        }
+                        busy = false;
+                    }
+                }
+            }
+#else
             for (int k = sub * 64 + lane; k < n; k += nsub * 64) {
                 trace_one<ANY>(sc, rays, stride, first + k, s_stack + threadIdx.x, out_prim, out_t, out_b1, out_b2, rs,
                                nvis, ntri);
                 nray++;
             }
+#endif
         }
     } else {
         for (long i = (long)blockIdx.x * PT_BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * PT_BLOCK) {

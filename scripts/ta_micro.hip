@@ -13,6 +13,7 @@
 struct Rec { double b[6]; int next; int pad[3]; };
 static_assert(sizeof(Rec) == 64, "");
 
+template <int NL>
 __global__ __launch_bounds__(256) void k_own(const Rec *__restrict__ recs, const int *__restrict__ start, int steps,
                                              int active, double *__restrict__ out) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -22,8 +23,13 @@ __global__ __launch_bounds__(256) void k_own(const Rec *__restrict__ recs, const
     if (((lane * 37) & 63) < active) {
         for (int s = 0; s < steps; s++) {
             const double2 *p = (const double2 *)(recs + i);
-            const double2 a = p[0], b = p[1], c = p[2], d = p[3];
-            acc += (a.x + a.y) + (b.x + b.y) + (c.x + c.y);
+            // NL of the record's four 16-byte quarters are loaded (the link is in the last one)
+            const double2 d = p[3];
+            double part = 0.;
+            if (NL > 1) { const double2 a = p[0]; part += a.x + a.y; }
+            if (NL > 2) { const double2 b = p[1]; part += b.x + b.y; }
+            if (NL > 3) { const double2 c = p[2]; part += c.x + c.y; }
+            acc += part;
             i = __double2loint(d.x);
         }
     }
@@ -88,7 +94,7 @@ int main(int argc, char **argv) {
         for (int v = 0; v < 2; v++) {
             for (int rep = 0; rep < 3; rep++) {
                 hipEventRecord(e0);
-                if (v == 0) hipLaunchKernelGGL(k_own, dim3(n / 256), dim3(256), 0, 0, d_r, d_s, steps, a, d_o);
+                if (v == 0) hipLaunchKernelGGL(k_own<4>, dim3(n / 256), dim3(256), 0, 0, d_r, d_s, steps, a, d_o);
                 else hipLaunchKernelGGL(k_coop, dim3(n / 256), dim3(256), 0, 0, d_r, d_s, steps, a, d_o);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 hipEventElapsedTime(&ms[v], e0, e1);
@@ -98,6 +104,18 @@ int main(int argc, char **argv) {
         long bad = 0;
         for (long i = 0; i < n; i++) bad += o1[i] != o2[i];
         const double fetches = (double)n * a / 64. * steps;
+        float msn[4] = {0, 0, 0, 0};
+        for (int nl = 1; nl <= 3; nl++)
+            for (int rep = 0; rep < 3; rep++) {
+                hipEventRecord(e0);
+                if (nl == 1) hipLaunchKernelGGL(k_own<1>, dim3(n / 256), dim3(256), 0, 0, d_r, d_s, steps, a, d_o);
+                if (nl == 2) hipLaunchKernelGGL(k_own<2>, dim3(n / 256), dim3(256), 0, 0, d_r, d_s, steps, a, d_o);
+                if (nl == 3) hipLaunchKernelGGL(k_own<3>, dim3(n / 256), dim3(256), 0, 0, d_r, d_s, steps, a, d_o);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                hipEventElapsedTime(&msn[nl], e0, e1);
+            }
+        printf("   loads per step 1/2/3/4: %.1f / %.1f / %.1f / %.1f G fetch/s\n", fetches / msn[1] / 1e6,
+               fetches / msn[2] / 1e6, fetches / msn[3] / 1e6, fetches / ms[0] / 1e6);
         printf("records %d active %2d/64: own %.3f ms (%.1f G fetch/s)  coop %.3f ms (%.1f G fetch/s)  mismatches %ld\n",
                n_rec, a, ms[0], fetches / ms[0] / 1e6, ms[1], fetches / ms[1] / 1e6, bad);
     }
