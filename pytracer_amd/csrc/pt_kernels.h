@@ -111,6 +111,12 @@ hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, co
                            double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 int pt_trace_occupancy(bool any, int stack);
 // the same trace with the first sc.n_top breadth-first nodes staged in LDS (1024-thread workgroups)
+// k_trace_meta: child/primitive words of all nodes in LDS (small trees); bytes of the table and of the whole block
+__host__ __device__ inline size_t pt_trace_meta_table_bytes(int n_nodes) { return (((size_t)n_nodes * 8) + 15) & ~(size_t)15; }
+size_t pt_trace_meta_lds(int stack, int n_nodes);
+hipError_t pt_launch_trace_meta(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                                long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
+                                double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 hipError_t pt_launch_trace_top(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
                                long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                                double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);

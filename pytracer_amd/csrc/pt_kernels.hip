@@ -162,9 +162,6 @@ __device__ __forceinline__ void trace_count(unsigned long long *counters, unsign
 // rays: component-major SoA [8][stride]; outputs per ray at the ray's own index.  ANY + rs.L:
 // the shadow "resolve" (K6) is fused: an unoccluded ray adds its precomputed contribution to
 // L[slot].
-#ifndef PT_REFILL
-#define PT_REFILL 0     // lanes that must be free before the wave fetches new rays (0: no refill)
-#endif
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 5   // <= 96 VGPRs: the two loops of traverse<> spill at 80 (6 waves/SIMD measured slower)
 #endif
@@ -198,9 +195,9 @@ __device__ __forceinline__ void trace_one(const DScene &sc, const double *__rest
 //  - segmented (the render queues, pt_kernels.h "segmented queues"): PT_SEG regions of `seg`
 //    entries, region r filled to seg_counts[r]; wave w serves region w % PT_SEG together with
 //    the other waves of the same residue.
-// Scheduling alternatives measured and rejected (while-while with per-lane refill, software
-// prefetch of the next node, scalar loads for wave-uniform nodes, dynamic and permuted chunk
-// assignment) are in the history of this file and in DESIGN.md "trace: what was tried".
+// Scheduling alternatives measured and rejected (while-while, lane refill, software prefetch of the
+// next node, scalar loads for wave-uniform nodes, dynamic and permuted chunk assignment) are in the
+// history of this file and in DESIGN.md "trace: what was tried".
 template <int STACK, bool ANY>
 __global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, const double *__restrict__ rays, long stride,
                                                     const int *__restrict__ seg_counts, long seg, int n_val,
@@ -217,99 +214,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, c
         if (sub < nsub) {
             const int n = seg_counts[r * PT_CNT_STRIDE];
             const long first = (long)r * seg;
-#if PT_REFILL
-            // Lane refill: the wave owns the 64-ray chunks sub, sub + nsub, ... of its region, numbered m = 0..M-1
-            // ray by ray; a lane whose ray is finished takes the wave's next unclaimed ray once PT_REFILL lanes are
-            // free (ballot + prefix count, no atomics), and every iteration is ONE node visit for all busy lanes.
-            const int stride64 = nsub * 64, base0 = sub * 64;
-            int M = 0;
-            if (base0 < n) {
-                const int nch = (n - base0 + stride64 - 1) / stride64;
-                const int last = n - (base0 + (nch - 1) * stride64);
-                M = (nch - 1) * 64 + (last < 64 ? last : 64);
-            }
-            int *stack = s_stack + threadIdx.x;
-            int m_next = 0;
-            bool busy = false;
-            Ray ry;
-            SlabRay sv;
-            long ri = 0;
-            int node_idx = 0, todo_idx = 0, result = 0;
-            double hb1 = 0., hb2 = 0.;
-            for (;;) {
-                const unsigned long long freem = __ballot(!busy);
-                const int nfree = __popcll(freem);
-                if (m_next < M && (nfree >= PT_REFILL || nfree == 64)) {
-                    if (!busy) {
-                        const int m = m_next + (int)__mbcnt_hi((unsigned)(freem >> 32), __mbcnt_lo((unsigned)freem, 0u));
-                        if (m < M) {
-                            ri = first + (long)(m >> 6) * stride64 + base0 + (m & 63);
-                            ry.o = mk3(rays[ri], rays[stride + ri], rays[2 * stride + ri]);
-                            ry.d = mk3(rays[3 * stride + ri], rays[4 * stride + ri], rays[5 * stride + ri]);
-                            ry.mint = rays[6 * stride + ri];
-                            ry.maxt = rays[7 * stride + ri];
-                            sv = slab_ray(sc, ry);
-                            node_idx = 0; todo_idx = 0; result = ANY ? 0 : -1; hb1 = 0.; hb2 = 0.;
-                            busy = true;
-                            nray++;
-                        }
-                    }
-                    m_next += nfree;
-                }
-                if (__ballot(busy) == 0ull) break;
-                if (busy) {
-                    const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node_idx);
-                    const double2 n0 = q[0], n1 = q[1], n2 = q[2];
-                    const int2 meta = *reinterpret_cast<const int2 *>(&q[3]);
-                    nvis++;
-                    const bool hitbox = sv.fast ? slab_hit<true>(n0, n1, n2, ry, sv) : slab_hit<false>(n0, n1, n2, ry, sv);
-                    const int nprim = meta.y & 0xFFFF;
-                    bool fin = false;
-                    if (hitbox && nprim > 0) {
-                        for (int i = 0; i < nprim; i++) {
-                            double t, b1, b2;
-                            ntri++;
-                            if (tri_test(sc.tris + meta.x + i, ry, t, b1, b2)) {
-                                if (ANY) { result = 1; fin = true; break; }
-                                result = meta.x + i;
-                                hb1 = b1; hb2 = b2;
-                                ry.maxt = t;
-                            }
-                        }
-                    }
-                    const bool inner = hitbox && nprim == 0;
-                    const bool neg = (sv.negmask >> (meta.y >> 16)) & 1;
-                    const int next = node_idx + 1;
-                    if (!inner && todo_idx == 0) fin = true;
-                    if (!fin) {
-                        int *slot = stack + (inner ? todo_idx : todo_idx - 1) * PT_BLOCK;
-                        if (inner) *slot = neg ? next : meta.x;
-                        const int popped = *slot;
-                        node_idx = inner ? (neg ? meta.x : next) : popped;
-                        todo_idx += inner ? 1 : -1;
-                    } else {
-                        if (out_prim) out_prim[ri] = result;
-                        if (!ANY) {
-                            if (out_t) out_t[ri] = ry.maxt;
-                            if (out_b1) out_b1[ri] = hb1;
-                            if (out_b2) out_b2[ri] = hb2;
-                        } else if (rs.L && result == 0) {
-                            const int slot = rs.slot[ri];
-                            unsafeAtomicAdd(rs.L + slot, rs.c[ri]);
-                            unsafeAtomicAdd(rs.L + rs.lstride + slot, rs.c[rs.cstride + ri]);
-                            unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + ri]);
-                        }
-                        busy = false;
-                    }
-                }
-            }
-#else
             for (int k = sub * 64 + lane; k < n; k += nsub * 64) {
                 trace_one<ANY>(sc, rays, stride, first + k, s_stack + threadIdx.x, out_prim, out_t, out_b1, out_b2, rs,
                                nvis, ntri);
                 nray++;
             }
-#endif
         }
     } else {
         for (long i = (long)blockIdx.x * PT_BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * PT_BLOCK) {
@@ -434,6 +343,134 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_top(DScene sc, const dou
         for (long i = (long)blockIdx.x * PT_TOP_BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * PT_TOP_BLOCK) one(i);
     }
     if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
+}
+
+// ---- child/primitive words in LDS ----------------------------------------------------------
+// k_trace_meta: for trees small enough (8 bytes per node beside the 1024 per-lane stacks: ~7 900 nodes at 24
+// levels), the (offset, n_prim | axis) word of EVERY node is staged in LDS, so a visit is three 16-byte vector
+// loads (the box) plus one ds_read_b64 instead of four vector loads — the vector-memory pipe, which bounds the
+// walk (scripts/ta_micro.hip: 252 vs 210 G visits/s), carries a quarter less.  Same walk as
+// traverse<>, bit for bit.
+template <bool ANY, bool FAST>
+__device__ __forceinline__ int traverse_meta_loop(const DScene &sc, const int2 *mlds, Ray &r, const SlabRay &sv,
+                                                  int *stack, double &b1o, double &b2o, unsigned &nvis, unsigned &ntri) {
+    int result = ANY ? 0 : -1;
+    int todo_idx = 0, node_idx = 0;
+    for (;;) {
+        const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node_idx);
+        const double2 n0 = q[0], n1 = q[1], n2 = q[2];
+        const int2 meta = mlds[node_idx];
+        nvis++;
+        const bool hitbox = slab_hit<FAST>(n0, n1, n2, r, sv);
+        const int nprim = meta.y & 0xFFFF;
+        if (hitbox && nprim > 0) {
+            for (int i = 0; i < nprim; i++) {
+                double t, b1, b2;
+                ntri++;
+                if (tri_test(sc.tris + meta.x + i, r, t, b1, b2)) {
+                    if (ANY) return 1;
+                    result = meta.x + i;
+                    b1o = b1; b2o = b2;
+                    r.maxt = t;
+                }
+            }
+        }
+        const bool inner = hitbox && nprim == 0;
+        const bool neg = (sv.negmask >> (meta.y >> 16)) & 1;
+        const int next = node_idx + 1;
+        if (!inner && todo_idx == 0) break;
+        int *slot = stack + (inner ? todo_idx : todo_idx - 1) * PT_TOP_BLOCK;
+        if (inner) *slot = neg ? next : meta.x;
+        const int popped = *slot;
+        node_idx = inner ? (neg ? meta.x : next) : popped;
+        todo_idx += inner ? 1 : -1;
+    }
+    return result;
+}
+
+template <bool ANY>
+__global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_meta(DScene sc, const double *__restrict__ rays, long stride,
+                                                             const int *__restrict__ seg_counts, long seg, int n_val,
+                                                             int *__restrict__ out_prim, double *__restrict__ out_t,
+                                                             double *__restrict__ out_b1, double *__restrict__ out_b2,
+                                                             ShadowResolve rs, unsigned long long *counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    int2 *mlds = reinterpret_cast<int2 *>(s_mem);
+    int *stack = reinterpret_cast<int *>(s_mem + pt_trace_meta_table_bytes(sc.n_nodes)) + threadIdx.x;
+    for (int k = threadIdx.x; k < sc.n_nodes; k += PT_TOP_BLOCK)
+        mlds[k] = make_int2(sc.nodes[k].offset, sc.nodes[k].nprim_axis);
+    __syncthreads();
+    unsigned nvis = 0, ntri = 0, nray = 0;
+    auto one = [&](long i) {
+        Ray r;
+        r.o = mk3(rays[i], rays[stride + i], rays[2 * stride + i]);
+        r.d = mk3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
+        r.mint = rays[6 * stride + i];
+        r.maxt = rays[7 * stride + i];
+        double b1 = 0., b2 = 0.;
+        int res = ANY ? 0 : -1;
+        if (sc.n_nodes > 0) {
+            const SlabRay sv = slab_ray(sc, r);
+            res = sv.fast ? traverse_meta_loop<ANY, true>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri)
+                          : traverse_meta_loop<ANY, false>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri);
+        }
+        if (out_prim) out_prim[i] = res;
+        if (!ANY) {
+            if (out_t) out_t[i] = r.maxt;
+            if (out_b1) out_b1[i] = b1;
+            if (out_b2) out_b2[i] = b2;
+        } else if (rs.L && res == 0) {
+            const int slot = rs.slot[i];
+            unsafeAtomicAdd(rs.L + slot, rs.c[i]);
+            unsafeAtomicAdd(rs.L + rs.lstride + slot, rs.c[rs.cstride + i]);
+            unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + i]);
+        }
+        nray++;
+    };
+    if (seg_counts) {
+        const int lane = threadIdx.x & 63;
+        const int wave = (int)((blockIdx.x * PT_TOP_BLOCK + threadIdx.x) >> 6);
+        const int nsub = (int)((gridDim.x * (PT_TOP_BLOCK / 64)) / PT_SEG);
+        const int r = wave % PT_SEG, sub = wave / PT_SEG;
+        if (sub < nsub) {
+            const int n = seg_counts[r * PT_CNT_STRIDE];
+            const long first = (long)r * seg;
+            for (int k = sub * 64 + lane; k < n; k += nsub * 64) one(first + k);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * PT_TOP_BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * PT_TOP_BLOCK) one(i);
+    }
+    if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
+}
+
+size_t pt_trace_meta_lds(int stack, int n_nodes) {
+    return pt_trace_meta_table_bytes(n_nodes) + (size_t)stack * PT_TOP_BLOCK * sizeof(int);
+}
+
+hipError_t pt_launch_trace_meta(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                                long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
+                                double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
+    static bool attr_set[2] = {false, false};
+    const size_t lds = pt_trace_meta_lds(stack, sc.n_nodes);
+    if (!attr_set[any ? 1 : 0]) {
+        hipError_t e = any ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_meta<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_meta<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[any ? 1 : 0] = true;
+    }
+    if (seg_counts) {   // whole sets of PT_SEG waves
+        const int per = PT_SEG / (PT_TOP_BLOCK / 64);
+        grid = ((grid + per - 1) / per) * per;
+    }
+    if (any)
+        hipLaunchKernelGGL((k_trace_meta<true>), dim3(grid), dim3(PT_TOP_BLOCK), lds, stream, sc, rays, stride, seg_counts,
+                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    else
+        hipLaunchKernelGGL((k_trace_meta<false>), dim3(grid), dim3(PT_TOP_BLOCK), lds, stream, sc, rays, stride, seg_counts,
+                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    return hipGetLastError();
 }
 
 // LDS bytes of k_trace_top for a tree that needs `stack` todo levels and stages n_top nodes

@@ -137,16 +137,18 @@ def test_axis_parallel_rays_on_box_planes(torch_cuda, ctx, golden_dir):
     assert (gs.node_visits, gs.tri_tests) == (os_.node_visits, os_.tri_tests)
 
 
-def test_top_of_tree_kernel_is_bitwise_the_same(torch_cuda, golden_dir, head):
-    """k_trace_top (first breadth-first nodes staged in LDS, PT_TRACE_TOP=1; off by default because it
-    measured slower) walks the same nodes in the same order: outputs and visit counts equal the oracle's."""
+@pytest.mark.parametrize('knob', [('PT_TRACE_TOP', '1'), ('PT_TRACE_META', '2'), ('PT_TRACE_META', '0')])
+def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head, knob):
+    """k_trace_top (first breadth-first nodes staged in LDS; default only for trees beyond the L2), k_trace_meta
+    (child/primitive words of all nodes in LDS; default for closest-hit launches on small trees) and the plain
+    k_trace walk the same nodes in the same order: outputs and visit counts equal the oracle's."""
     import oracle_lib as O
     from pytracer_amd._lib import Context
-    os.environ['PT_TRACE_TOP'] = '1'
+    os.environ[knob[0]] = knob[1]
     try:
         c = Context(0)
     finally:
-        del os.environ['PT_TRACE_TOP']
+        del os.environ[knob[0]]
     try:
         cases = [(head[1], head[2], rays_from_log(load(golden_dir, 'head_path_32x32x4.npz')['log_rays']))]
         for name in ('bvh_soup2000.npz', 'bvh_soup500dup.npz'):
