@@ -211,6 +211,8 @@ def main():
                 traffic = None
         roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': name,
+                'kernel_note': 'closest-hit launches run k_trace_meta<false> (child words in LDS) on trees of up to ~7900 '
+                               'nodes, k_trace<STACK,false> otherwise; profiles/ lists the symbol under full_name',
                 'launches': int(launches), 'avg_launch_ms': ms / max(launches, 1),
                 'algorithmic_bytes_per_launch': abytes / max(launches, 1),
                 'rays': int(nr), 'node_visits_per_ray': nv / max(nr, 1), 'tri_tests_per_ray': nt / max(nr, 1),

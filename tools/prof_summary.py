@@ -24,6 +24,9 @@ def short(name):
     m = re.match(r'(?:void )?(k_trace)<(\d+), (true|false)>', name)
     if m:
         return 'k_trace<%s>' % ('any' if m.group(3) == 'true' else 'closest')
+    m = re.match(r'(?:void )?k_trace_(?:meta|top)<(true|false)>', name)   # LDS-staged variants of the same walk
+    if m:
+        return 'k_trace<%s>' % ('any' if m.group(1) == 'true' else 'closest')
     m = re.match(r'(?:void )?(k_[a-z_]+)(<\d+>)?', name)
     return (m.group(1) + (m.group(2) or '')) if m else name[:60]
 
