@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 6
+#define PT_ABI_VERSION 7
 
 typedef enum {
     PT_OK = 0,
@@ -56,7 +56,9 @@ typedef enum {
 
 typedef struct {
     int32_t type;       /* pt_lobe_type */
-    int32_t _pad;
+    int32_t tex;        /* 0: R is the lobe's colour; k > 0: colour = R * clip(texture k-1 at the hit)
+                           (pt_scene_desc.textures; Material.get_bsdf evaluates Kd/Ks per hit,
+                           material/material.py:131,175-176) */
     double R[3];        /* RGB scale (Spectrum = RGBSpectrum, spectral/spectrum.py:610) */
     double a, b, c;
     double eta[3], k[3];/* conductor lobes only */
@@ -67,6 +69,30 @@ typedef struct {
     int32_t _pad;
     pt_lobe lobes[PT_MAX_LOBES];
 } pt_material;
+
+/* ---- spectrum textures of a constant-free kind (texture/texture/__init__.py) over constant
+ * children, with their mappings (texture/texturemap/__init__.py).  Materials hand textures a COPY of
+ * the shading geometry whose screen-space differentials are zero (material.py:128,172: dg_s.copy(),
+ * geometry/diffgeom.py:21-42), so the closed-form antialiasing of the checkerboard always takes its
+ * "filter inside one check" branch and equals point sampling (texture/__init__.py:156-166). */
+typedef enum {
+    PT_TEX_CHECKER2D = 0,   /* Chekcerboard2DTexture :119-179, aa 'none' or 'closedform'; v[0], v[1]   */
+    PT_TEX_CHECKER3D = 1,   /* Checkboard3DTexture :182-196; v[0], v[1]                                */
+    PT_TEX_BILERP = 2,      /* BilerpTexture :85-104; v[0..3] = v00, v01, v10, v11                      */
+    PT_TEX_UV = 3           /* UVTexture :107-116: (s - floor s, t - floor t, 0)                        */
+} pt_tex_kind;
+typedef enum {
+    PT_MAP_UV = 0,          /* UVMapping2D texturemap:38-52; m = su, sv, du, dv                         */
+    PT_MAP_PLANAR = 1,      /* PlannarMapping2D :135-149; m = vs[3], vt[3], ds, dt                      */
+    PT_MAP_SPHERICAL = 2,   /* SphericalMapping2D :55-68; m = w2t 4x4 row-major                         */
+    PT_MAP_IDENTITY3D = 3   /* IdentityMapping3D :175-180 (3D textures); m = w2t 4x4 row-major          */
+} pt_map_kind;
+typedef struct {
+    int32_t kind;       /* pt_tex_kind */
+    int32_t mapping;    /* pt_map_kind */
+    double m[16];
+    double v[4][3];
+} pt_texture;
 
 /* ---- lights (light/light.py) ------------------------------------------------------ */
 typedef enum {
@@ -101,6 +127,8 @@ typedef struct {
     const int32_t *tri_flip;     /* host [n_tris]: shape.ro ^ transform_swaps_handedness */
     const pt_material *materials;/* host [n_materials] */
     const pt_light *lights;      /* host [n_lights] */
+    int32_t n_textures, _pad;
+    const pt_texture *textures;  /* host [n_textures]; referenced by pt_lobe.tex */
 } pt_scene_desc;
 
 /* ---- camera (camera/projective.py:42-59; OrthoCamera :65-127; PerspectiveCamera

@@ -94,6 +94,8 @@ typedef struct {
     int32_t *tri_mat, *tri_flip;
     pt_material *materials;
     pt_light *lights;
+    int32_t n_textures;
+    pt_texture *textures;
 } oscene;
 
 static void *dupmem(const void *p, size_t n) {
@@ -101,6 +103,8 @@ static void *dupmem(const void *p, size_t n) {
     if (n) memcpy(q, p, n);
     return q;
 }
+
+int pto_scene_destroy(void *p);
 
 int pto_scene_create(const pt_scene_desc *d, void **out) {
     if (!d || !out) return PT_ERR_ARG;
@@ -114,6 +118,14 @@ int pto_scene_create(const pt_scene_desc *d, void **out) {
     s->tri_flip = (int32_t *)dupmem(d->tri_flip, sizeof(int32_t) * d->n_tris);
     s->materials = (pt_material *)dupmem(d->materials, sizeof(pt_material) * d->n_materials);
     s->lights = (pt_light *)dupmem(d->lights, sizeof(pt_light) * d->n_lights);
+    s->n_textures = d->n_textures;
+    s->textures = (pt_texture *)dupmem(d->textures, sizeof(pt_texture) * d->n_textures);
+    for (int i = 0; i < d->n_materials; i++)
+        for (int k = 0; k < s->materials[i].n_lobes; k++)
+            if (s->materials[i].lobes[k].tex < 0 || s->materials[i].lobes[k].tex > d->n_textures) {
+                pto_scene_destroy(s);
+                return PT_ERR_ARG;
+            }
     *out = s;
     return PT_OK;
 }
@@ -122,7 +134,7 @@ int pto_scene_destroy(void *p) {
     oscene *s = (oscene *)p;
     if (!s) return PT_OK;
     free(s->node_bounds); free(s->node_meta); free(s->tri_verts); free(s->tri_mat);
-    free(s->tri_flip); free(s->materials); free(s->lights); free(s);
+    free(s->tri_flip); free(s->materials); free(s->lights); free(s->textures); free(s);
     return PT_OK;
 }
 
@@ -247,7 +259,86 @@ typedef struct {
     v3 dpdu, dpdv;
     double u, v, rEps;
     const pt_material *mat;
+    pt_material tmat;      /* the material with its textured lobe colours evaluated at this vertex */
 } overtex;
+
+/* ---- textures (texture/texture/__init__.py) over constant children, evaluated where Material.get_bsdf
+ * evaluates Kd / Ks (material/material.py:131,175-176) on a copy of the shading geometry whose differentials
+ * are zero (dg_s.copy(), geometry/diffgeom.py:21-42,47-48), so Chekcerboard2DTexture's closed-form
+ * antialiasing takes its "inside one check" branch (texture/__init__.py:156-166) = point sampling. */
+static v3 xform_point(const double *m, v3 p) {           /* Transform.__call__(Point), transform/__init__.py:55-60 */
+    double x = ((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3];
+    double y = ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7];
+    double z = ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11];
+    double w = ((m[12] * p.x + m[13] * p.y) + m[14] * p.z) + m[15];
+    if (w < 1. - PT_EPS || w > 1. + PT_EPS) { x /= w; y /= w; z /= w; }      /* util.ne_unity */
+    return V(x, y, z);
+}
+static void tex_map2d(const pt_texture *t, const overtex *vx, double *s_out, double *t_out) {
+    const double *m = t->m;
+    switch (t->mapping) {
+    case PT_MAP_UV:            /* texturemap:45-47 */
+        *s_out = m[0] * vx->u + m[2];
+        *t_out = m[1] * vx->v + m[3];
+        return;
+    case PT_MAP_PLANAR: {      /* texturemap:142-145 */
+        v3 v = vx->p;
+        *s_out = m[6] + vdot(v, V(m[0], m[1], m[2]));
+        *t_out = m[7] + vdot(v, V(m[3], m[4], m[5]));
+        return;
+    }
+    default: {                 /* PT_MAP_SPHERICAL, texturemap:59-68 */
+        v3 v = vnormalize(xform_point(m, vx->p));
+        double cz = v.z < -1. ? -1. : (v.z > 1. ? 1. : v.z);
+        double theta = acos(cz);                          /* geometry/utility.py:106-112 */
+        double ph = atan2(v.y, v.x);
+        if (!(ph > 0.)) ph = ph + 2. * M_PI;              /* geometry/utility.py:121-122 */
+        *s_out = theta * (1. / M_PI);
+        *t_out = ph * (1. / (2. * M_PI));
+        return;
+    }
+    }
+}
+static v3 tex_eval(const pt_texture *t, const overtex *vx) {
+    double s = 0., tt = 0.;
+    switch (t->kind) {
+    case PT_TEX_CHECKER2D:     /* :147-152 / :162-166 */
+        tex_map2d(t, vx, &s, &tt);
+        return ((((long long)floor(s) + (long long)floor(tt)) & 1) == 0) ? V(t->v[0][0], t->v[0][1], t->v[0][2])
+                                                                          : V(t->v[1][0], t->v[1][1], t->v[1][2]);
+    case PT_TEX_CHECKER3D: {   /* :191-196 */
+        v3 p = xform_point(t->m, vx->p);
+        return ((((long long)floor(p.x) + (long long)floor(p.y) + (long long)floor(p.z)) & 1) == 0)
+                   ? V(t->v[0][0], t->v[0][1], t->v[0][2]) : V(t->v[1][0], t->v[1][1], t->v[1][2]);
+    }
+    case PT_TEX_BILERP: {      /* :101-104 */
+        tex_map2d(t, vx, &s, &tt);
+        v3 a = vmul(V(t->v[0][0], t->v[0][1], t->v[0][2]), (1. - s) * (1. - tt));
+        v3 b = vmul(V(t->v[1][0], t->v[1][1], t->v[1][2]), (1. - s) * tt);
+        v3 c = vmul(V(t->v[2][0], t->v[2][1], t->v[2][2]), (1. - tt) * s);
+        v3 d = vmul(V(t->v[3][0], t->v[3][1], t->v[3][2]), s * tt);
+        return vadd(vadd(vadd(a, b), c), d);
+    }
+    default:                   /* PT_TEX_UV :114-116 */
+        tex_map2d(t, vx, &s, &tt);
+        return V(s - floor(s), tt - floor(tt), 0.);
+    }
+}
+/* lobe colour = R * util.clip(texture(dgs)) (material.py:131: r = util.clip(self.Kd(dgs))) */
+static void apply_textures(const oscene *sc, overtex *vx) {
+    int any = 0;
+    for (int k = 0; k < vx->mat->n_lobes; k++) any |= vx->mat->lobes[k].tex;
+    if (!any) return;
+    vx->tmat = *vx->mat;
+    for (int k = 0; k < vx->tmat.n_lobes; k++) {
+        pt_lobe *l = &vx->tmat.lobes[k];
+        if (!l->tex) continue;
+        v3 c = tex_eval(sc->textures + (l->tex - 1), vx);
+        c = V(c.x < 0. ? 0. : c.x, c.y < 0. ? 0. : c.y, c.z < 0. ? 0. : c.z);
+        l->R[0] *= c.x; l->R[1] *= c.y; l->R[2] *= c.z;
+    }
+    vx->mat = &vx->tmat;
+}
 
 /* Triangle.intersect tail (triangle.py:209-243) with the default uvs (0,0),(1,0),(1,1)
  * (triangle.py:125-127), DifferentialGeometry.__init__ (geometry/diffgeom.py:21-42) and
@@ -274,6 +365,7 @@ static void make_vertex(const oscene *s, const oray *r, const ohit *h, overtex *
     vx->sn = vnormalize(vx->dpdu);
     vx->tn = vcross(vx->nn, vx->sn);
     vx->mat = s->materials + s->tri_mat[h->prim];
+    apply_textures(s, vx);
 }
 
 /* BSDF.w2l, bsdf.py:187-194 */

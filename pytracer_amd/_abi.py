@@ -1,7 +1,7 @@
 """ctypes mirror of include/pytracer_hip.h (struct layouts and enums only)."""
 import ctypes as C
 
-PT_ABI_VERSION = 6
+PT_ABI_VERSION = 7
 PT_MAX_LOBES = 5
 
 PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
@@ -9,19 +9,25 @@ PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 
 (PT_LOBE_LAMBERT, PT_LOBE_OREN_NAYAR, PT_LOBE_MICROFACET_BLINN, PT_LOBE_SPEC_REFLECT, PT_LOBE_SPEC_TRANSMIT,
  PT_LOBE_MICROFACET_BLINN_COND) = range(6)
 PT_LIGHT_DIFFUSE_SPHERE, PT_LIGHT_SPOT, PT_LIGHT_POINT = range(3)
+PT_TEX_CHECKER2D, PT_TEX_CHECKER3D, PT_TEX_BILERP, PT_TEX_UV = range(4)
+PT_MAP_UV, PT_MAP_PLANAR, PT_MAP_SPHERICAL, PT_MAP_IDENTITY3D = range(4)
 PT_INTEG_DIRECT, PT_INTEG_PATH, PT_INTEG_WHITTED = 0, 1, 2
 PT_CAM_PERSPECTIVE, PT_CAM_ORTHO = 0, 1
 PT_BVH_SAH, PT_BVH_MIDDLE = 0, 1
 
 
 class pt_lobe(C.Structure):
-    _fields_ = [('type', C.c_int32), ('_pad', C.c_int32), ('R', C.c_double * 3),
+    _fields_ = [('type', C.c_int32), ('tex', C.c_int32), ('R', C.c_double * 3),
                 ('a', C.c_double), ('b', C.c_double), ('c', C.c_double),
                 ('eta', C.c_double * 3), ('k', C.c_double * 3)]
 
 
 class pt_material(C.Structure):
     _fields_ = [('n_lobes', C.c_int32), ('_pad', C.c_int32), ('lobes', pt_lobe * PT_MAX_LOBES)]
+
+
+class pt_texture(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('mapping', C.c_int32), ('m', C.c_double * 16), ('v', (C.c_double * 3) * 4)]
 
 
 class pt_light(C.Structure):
@@ -35,7 +41,8 @@ class pt_scene_desc(C.Structure):
     _fields_ = [('n_nodes', C.c_int32), ('n_tris', C.c_int32), ('n_materials', C.c_int32), ('n_lights', C.c_int32),
                 ('node_bounds', C.c_void_p), ('node_meta', C.c_void_p), ('tri_verts', C.c_void_p),
                 ('tri_mat', C.c_void_p), ('tri_flip', C.c_void_p),
-                ('materials', C.POINTER(pt_material)), ('lights', C.POINTER(pt_light))]
+                ('materials', C.POINTER(pt_material)), ('lights', C.POINTER(pt_light)),
+                ('n_textures', C.c_int32), ('_pad', C.c_int32), ('textures', C.POINTER(pt_texture))]
 
 
 class pt_camera(C.Structure):

@@ -17,7 +17,7 @@ struct pt_ctx {
     // scene (device)
     bool have_scene;
     DScene sc;
-    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top;
+    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch;
     int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
     int meta_stack;          // todo levels of k_trace_meta's LDS stacks (0: the tree's child words do not fit in LDS)
     int use_meta;            // k_trace_meta when the tree fits: PT_TRACE_META=0 never, 1 (default) closest-hit launches
@@ -162,7 +162,8 @@ static void collect_timing(pt_ctx *c, pt_stats *stats) {
 }
 
 static void free_scene(pt_ctx *c) {
-    void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top};
+    void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top,
+                   &c->d_tex, &c->d_tex_scratch};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -233,8 +234,13 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     if (d->n_nodes < 0 || d->n_tris < 0 || d->n_materials < 0 || d->n_lights < 0) return fail(c, PT_ERR_ARG, "negative count");
     if ((d->n_nodes && (!d->node_bounds || !d->node_meta)) ||
         (d->n_tris && (!d->tri_verts || !d->tri_mat || !d->tri_flip)) || (d->n_materials && !d->materials) ||
-        (d->n_lights && !d->lights))
+        (d->n_lights && !d->lights) || d->n_textures < 0 || (d->n_textures && !d->textures))
         return fail(c, PT_ERR_ARG, "null array");
+    for (int i = 0; i < d->n_textures; i++)
+        if (d->textures[i].kind < 0 || d->textures[i].kind > PT_TEX_UV || d->textures[i].mapping < 0 ||
+            d->textures[i].mapping > PT_MAP_IDENTITY3D ||
+            ((d->textures[i].kind == PT_TEX_CHECKER3D) != (d->textures[i].mapping == PT_MAP_IDENTITY3D)))
+            return fail(c, PT_ERR_ARG, "texture %d: kind / mapping", i);
     if (d->n_lights > 16) return fail(c, PT_ERR_CAPACITY, "at most 16 lights");
     HIPCHK(c, hipSetDevice(c->device));
     int depth = 0;
@@ -249,6 +255,7 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
         if (m.n_lobes < 0 || m.n_lobes > PT_MAX_LOBES) return fail(c, PT_ERR_ARG, "material %d: n_lobes", i);
         for (int k = 0; k < m.n_lobes; k++) {
             if (m.lobes[k].type < 0 || m.lobes[k].type > PT_LOBE_MICROFACET_BLINN_COND) return fail(c, PT_ERR_ARG, "material %d: lobe type", i);
+            if (m.lobes[k].tex < 0 || m.lobes[k].tex > d->n_textures) return fail(c, PT_ERR_ARG, "material %d: texture index", i);
             spec |= m.lobes[k].type == PT_LOBE_SPEC_REFLECT;
         }
     }
@@ -336,6 +343,13 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     HIPCHK(c, upload(&c->d_flip, d->tri_flip, (size_t)d->n_tris));
     HIPCHK(c, upload(&c->d_mats, d->materials, (size_t)d->n_materials));
     HIPCHK(c, upload(&c->d_lights, d->lights, (size_t)d->n_lights));
+    if (d->n_textures > 0) {
+        HIPCHK(c, upload(&c->d_tex, d->textures, (size_t)d->n_textures));
+        // one pt_material per thread of the largest shade grid (pt_render: n_cu * 4 blocks, rounded up to a
+        // whole set of PT_SEG waves)
+        const size_t threads = ((size_t)c->n_cu * 4 + PT_SEG_BLOCKS) * PT_BLOCK;
+        HIPCHK(c, hipMalloc(&c->d_tex_scratch, threads * sizeof(pt_material)));
+    }
     DScene &s = c->sc;
     s.nodes = (const GNode *)c->d_nodes;
     s.top = n_top ? (const TopNode *)c->d_top : nullptr;
@@ -351,6 +365,8 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     s.tri_flip = (const int32_t *)c->d_flip;
     s.mats = (const pt_material *)c->d_mats;
     s.lights = (const pt_light *)c->d_lights;
+    s.textures = (const pt_texture *)c->d_tex;
+    s.tex_scratch = (pt_material *)c->d_tex_scratch;
     s.n_nodes = d->n_nodes; s.n_tris = d->n_tris; s.n_mats = d->n_materials; s.n_lights = d->n_lights;
     memcpy(s.le_sum, le, sizeof(le));
     c->stack_need = std::max(depth, 1);

@@ -107,6 +107,8 @@ struct DScene {
     const int32_t *tri_flip;
     const pt_material *mats;
     const pt_light *lights;
+    const pt_texture *textures;   // referenced by pt_lobe.tex (k > 0: textures[k-1])
+    pt_material *tex_scratch;     // one pt_material per shading thread: the textured material at its vertex
     int32_t n_nodes, n_tris, n_mats, n_lights;
     double le_sum[3];          // Σ light.le over lights (DiffuseAreaLight.le = emit, light.py:503-505)
 };
@@ -143,6 +145,84 @@ __device__ inline void make_vertex(const DScene &sc, const Ray &r, int prim, dou
     vx.sn = normalize3(dpdu);
     vx.tn = cross3(vx.nn, vx.sn);
     vx.mat = sc.mats + sc.tri_mat[prim];
+}
+
+// ---- textures (texture/texture/__init__.py) over constant children, evaluated where Material.get_bsdf
+// evaluates Kd / Ks (material/material.py:131,175-176) on a copy of the shading geometry whose differentials are
+// zero (dg_s.copy(), geometry/diffgeom.py:21-42,47-48): Chekcerboard2DTexture's closed-form antialiasing then
+// takes its "inside one check" branch (texture/__init__.py:156-166) = point sampling.
+__device__ inline d3 xform_point(const double *m, d3 p) {       // Transform.__call__(Point), transform/__init__.py:55-60
+    double x = ((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3];
+    double y = ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7];
+    double z = ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11];
+    double w = ((m[12] * p.x + m[13] * p.y) + m[14] * p.z) + m[15];
+    if (w < 1. - PT_EPS || w > 1. + PT_EPS) { x /= w; y /= w; z /= w; }     // util.ne_unity
+    return mk3(x, y, z);
+}
+__device__ inline void tex_map2d(const pt_texture &t, d3 p, double u, double v, double &s_out, double &t_out) {
+    const double *m = t.m;
+    if (t.mapping == PT_MAP_UV) {                  // texturemap:45-47
+        s_out = m[0] * u + m[2];
+        t_out = m[1] * v + m[3];
+    } else if (t.mapping == PT_MAP_PLANAR) {       // texturemap:142-145
+        s_out = m[6] + dot3(p, mk3(m[0], m[1], m[2]));
+        t_out = m[7] + dot3(p, mk3(m[3], m[4], m[5]));
+    } else {                                       // PT_MAP_SPHERICAL, texturemap:59-68
+        d3 w = normalize3(xform_point(m, p));
+        double cz = w.z < -1. ? -1. : (w.z > 1. ? 1. : w.z);
+        double theta = acos(cz);                   // geometry/utility.py:106-112
+        double ph = atan2(w.y, w.x);
+        if (!(ph > 0.)) ph = ph + 2. * PT_PI;      // geometry/utility.py:121-122
+        s_out = theta * PT_INV_PI;
+        t_out = ph * PT_INV_2PI;
+    }
+}
+__device__ inline d3 tex_eval(const pt_texture &t, d3 p, double u, double v) {
+    double s = 0., tt = 0.;
+    switch (t.kind) {
+    case PT_TEX_CHECKER2D:                         // :147-152 / :162-166
+        tex_map2d(t, p, u, v, s, tt);
+        return ((((long long)floor(s) + (long long)floor(tt)) & 1) == 0) ? mk3(t.v[0][0], t.v[0][1], t.v[0][2])
+                                                                          : mk3(t.v[1][0], t.v[1][1], t.v[1][2]);
+    case PT_TEX_CHECKER3D: {                       // :191-196
+        d3 q = xform_point(t.m, p);
+        return ((((long long)floor(q.x) + (long long)floor(q.y) + (long long)floor(q.z)) & 1) == 0)
+                   ? mk3(t.v[0][0], t.v[0][1], t.v[0][2]) : mk3(t.v[1][0], t.v[1][1], t.v[1][2]);
+    }
+    case PT_TEX_BILERP: {                          // :101-104
+        tex_map2d(t, p, u, v, s, tt);
+        d3 a = mk3(t.v[0][0], t.v[0][1], t.v[0][2]) * ((1. - s) * (1. - tt));
+        d3 b = mk3(t.v[1][0], t.v[1][1], t.v[1][2]) * ((1. - s) * tt);
+        d3 c = mk3(t.v[2][0], t.v[2][1], t.v[2][2]) * ((1. - tt) * s);
+        d3 e = mk3(t.v[3][0], t.v[3][1], t.v[3][2]) * (s * tt);
+        return ((a + b) + c) + e;
+    }
+    default:                                       // PT_TEX_UV :114-116
+        tex_map2d(t, p, u, v, s, tt);
+        return mk3(s - floor(s), tt - floor(tt), 0.);
+    }
+}
+// A material with textured lobes is evaluated ONCE per vertex into the calling thread's scratch record
+// (lobe colour = R * util.clip(texture(dgs)), material.py:131) and the vertex points at that copy: the BSDF code
+// reads lobes through vx.mat and never knows.  Materials without textures (tex == 0 in every lobe) pay one test.
+__device__ inline void apply_textures(const DScene &sc, Vertex &vx, double b1, double b2, pt_material *scratch) {
+    const pt_material &m = *vx.mat;
+    int any = 0;
+    for (int k = 0; k < m.n_lobes; k++) any |= m.lobes[k].tex;
+    if (!any) return;
+    // Triangle.intersect, triangle.py:228-231 with the default uvs (0,0),(1,0),(1,1)
+    const double b0 = 1.0 - b1 - b2;
+    const double u = (b0 * 0. + b1 * 1.) + b2 * 1., v = (b0 * 0. + b1 * 0.) + b2 * 1.;
+    *scratch = m;
+    for (int k = 0; k < m.n_lobes; k++) {
+        const int ti = m.lobes[k].tex;
+        if (!ti) continue;
+        d3 c = tex_eval(sc.textures[ti - 1], vx.p, u, v);
+        scratch->lobes[k].R[0] = m.lobes[k].R[0] * max0(c.x);
+        scratch->lobes[k].R[1] = m.lobes[k].R[1] * max0(c.y);
+        scratch->lobes[k].R[2] = m.lobes[k].R[2] * max0(c.z);
+    }
+    vx.mat = scratch;
 }
 
 // BSDF.w2l, bsdf.py:187-194

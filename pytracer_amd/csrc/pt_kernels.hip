@@ -786,7 +786,8 @@ __device__ __forceinline__ void push_shadow(const ShadowQueue &sh, int region, b
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2
 #endif
-template <int KIND>
+// TEX: the scene has textured lobes (compile-time, so that scenes without textures run the kernel unchanged)
+template <int KIND, bool TEX>
 __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
                                                     int level, Queue qin, HitList hl, Queue qout, ShadowQueue sh,
                                                     PathState st) {
@@ -818,6 +819,8 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
             ray.o = mk3(qin.rays[i], qin.rays[S + i], qin.rays[2 * S + i]);
             ray.d = mk3(qin.rays[3 * S + i], qin.rays[4 * S + i], qin.rays[5 * S + i]);
             make_vertex(sc, ray, prim, qin.t[i], vx);
+            if (TEX)
+                apply_textures(sc, vx, qin.b1[i], qin.b2[i], sc.tex_scratch + ((size_t)blockIdx.x * PT_BLOCK + threadIdx.x));
             wo = -ray.d;
             int px, py, si;
             uint32_t sid;
@@ -988,12 +991,12 @@ hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene 
                            int level, const Queue &qin, const HitList &hl, const Queue &qout, const ShadowQueue &sh,
                            const PathState &st) {
     grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
-    if (kind == PT_INTEG_DIRECT)
-        hipLaunchKernelGGL((k_shade<PT_INTEG_DIRECT>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st);
-    else if (kind == PT_INTEG_WHITTED)
-        hipLaunchKernelGGL((k_shade<PT_INTEG_WHITTED>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st);
-    else
-        hipLaunchKernelGGL((k_shade<PT_INTEG_PATH>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st);
+#define PT_SHADE(K, T) hipLaunchKernelGGL((k_shade<K, T>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st)
+    const bool tex = sc.textures != nullptr;
+    if (kind == PT_INTEG_DIRECT) { if (tex) PT_SHADE(PT_INTEG_DIRECT, true); else PT_SHADE(PT_INTEG_DIRECT, false); }
+    else if (kind == PT_INTEG_WHITTED) { if (tex) PT_SHADE(PT_INTEG_WHITTED, true); else PT_SHADE(PT_INTEG_WHITTED, false); }
+    else { if (tex) PT_SHADE(PT_INTEG_PATH, true); else PT_SHADE(PT_INTEG_PATH, false); }
+#undef PT_SHADE
     return hipGetLastError();
 }
 

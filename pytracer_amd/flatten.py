@@ -7,9 +7,11 @@ Only PUBLIC attributes of the reference classes are read:
 format (``flat_scene_from_npz``), which is how the GPU box — where the reference does not
 exist — gets its scenes.
 
-Materials are evaluated at flatten time (every supported texture is a ConstantTexture) into
-the ordered lobe list ``Material.get_bsdf`` would push
-(reference pytracer/material/material.py:122-141, 166-189, 208-222, 280-299, 329-364).
+Materials are evaluated at flatten time into the ordered lobe list ``Material.get_bsdf`` would push
+(reference pytracer/material/material.py:122-141, 166-189, 208-222, 280-299, 329-364).  Parameters are
+ConstantTextures (or Scale/Mix of constants, folded here); the spectrum parameters whose lobe is pushed
+unconditionally — Matte Kd, Plastic Kd and Ks — may also be a checkerboard / bilerp / UV texture
+(``texture_record``), evaluated per hit on the device.
 """
 import ctypes as C
 
@@ -43,24 +45,36 @@ def _blinn_exponent(rough):
     return float(np.clip(1. / rough, -np.inf, 10000.))
 
 
+def _colour(v):
+    """(R, extras) of a spectrum parameter: a constant is clipped here; a texture record (dict, see
+    texture_record) leaves R = 1 and rides along as the lobe's last tuple element {'tex': record}."""
+    if isinstance(v, dict):
+        return np.ones(3), ({'tex': v},)
+    return _clip(_spec(v)), ()
+
+
 def lobes_from_params(kind, **p):
     """Ordered lobe list [(type, R[3], a, b, c)] for one material record.
 
     kind: 'matte' | 'uber' | 'plastic' | 'mirror' | 'glass' | 'metal'
-    (a conductor lobe carries two more entries: eta[3], k[3])
+    (a conductor lobe carries two more entries: eta[3], k[3]; a textured lobe ends with {'tex': record})
     """
     out = []
+    for name, v in p.items():
+        if isinstance(v, dict) and not (kind == 'matte' and name == 'Kd') and not (kind == 'plastic' and name in ('Kd', 'Ks')):
+            raise NotImplementedError('a non-constant texture is supported for Matte Kd and Plastic Kd / Ks only '
+                                      '(%s %s decides per hit which lobes exist)' % (kind, name))
     if kind == 'matte':                         # material.py:122-141
-        r = _clip(_spec(p['Kd']))
+        r, ex = _colour(p['Kd'])
         sigma = float(np.clip(p['sigma'], 0., 90.))
         if sigma == 0.:
-            out.append((A.PT_LOBE_LAMBERT, r, 0., 0., 0.))
+            out.append((A.PT_LOBE_LAMBERT, r, 0., 0., 0.) + ex)
         else:                                   # OrenNayar.__init__, orennayar.py:36-42
             sig = np.deg2rad(sigma)
             sig_sq = sig * sig
             a = 1. - (sig_sq / (2. * (sig_sq + 0.33)))
             b = .45 * sig_sq / (sig_sq + .09)
-            out.append((A.PT_LOBE_OREN_NAYAR, r, float(a), float(b), 0.))
+            out.append((A.PT_LOBE_OREN_NAYAR, r, float(a), float(b), 0.) + ex)
     elif kind == 'uber':                        # material.py:329-364
         op = _clip(_spec(p['opacity']))
         if not np.array_equal(op, [1., 1., 1.]):
@@ -79,9 +93,10 @@ def lobes_from_params(kind, **p):
         if not _is_black(kt):
             out.append((A.PT_LOBE_SPEC_TRANSMIT, kt, e, 1., 0.))
     elif kind == 'plastic':                     # material.py:166-189
-        out.append((A.PT_LOBE_LAMBERT, _clip(_spec(p['Kd'])), 0., 0., 0.))
-        out.append((A.PT_LOBE_MICROFACET_BLINN, _clip(_spec(p['Ks'])), 1.5, 1.,
-                    _blinn_exponent(float(p['roughness']))))
+        kd, exd = _colour(p['Kd'])
+        ks, exs = _colour(p['Ks'])
+        out.append((A.PT_LOBE_LAMBERT, kd, 0., 0., 0.) + exd)
+        out.append((A.PT_LOBE_MICROFACET_BLINN, ks, 1.5, 1., _blinn_exponent(float(p['roughness']))) + exs)
     elif kind == 'mirror':                      # material.py:208-222
         r = _clip(_spec(p['Kr']))
         if not _is_black(r):
@@ -104,11 +119,79 @@ def lobes_from_params(kind, **p):
     return out
 
 
-def _tex(t):
-    """Evaluate a ConstantTexture (texture/texture/__init__.py:41-46)."""
-    if type(t).__name__ != 'ConstantTexture':
-        raise NotImplementedError('only ConstantTexture is on the supported hot path, got %s' % type(t).__name__)
-    return t.value
+def _const(t):
+    """Value of a texture that is constant over the surface: ConstantTexture (texture/__init__.py:41-46),
+    ScaleTexture (:49-61) and MixTexture (:64-82) of such; None otherwise."""
+    nm = type(t).__name__
+    if nm == 'ConstantTexture':
+        return t.value
+    if nm == 'ScaleTexture':
+        a, b = _const(t.tex1), _const(t.tex2)
+        return None if a is None or b is None else np.asarray(a, np.float64) * np.asarray(b, np.float64)
+    if nm == 'MixTexture':
+        a, b, m = _const(t.tex1), _const(t.tex2), _const(t.amt)
+        if a is None or b is None or m is None:
+            return None
+        return (1. - m) * np.asarray(a, np.float64) + m * np.asarray(b, np.float64)
+    return None
+
+
+def _mapping_record(mp):
+    nm = type(mp).__name__
+    m = np.zeros(16)
+    if nm == 'UVMapping2D':
+        m[0:4] = [mp.su, mp.sv, mp.du, mp.dv]
+        return A.PT_MAP_UV, m
+    if nm == 'PlannarMapping2D':
+        m[0:3], m[3:6], m[6], m[7] = np.asarray(mp.vs, np.float64), np.asarray(mp.vt, np.float64), mp.ds, mp.dt
+        return A.PT_MAP_PLANAR, m
+    if nm == 'SphericalMapping2D':
+        return A.PT_MAP_SPHERICAL, np.asarray(mp.w2t.m, np.float64).ravel().copy()
+    if nm == 'IdentityMapping3D':
+        return A.PT_MAP_IDENTITY3D, np.asarray(mp.w2t.m, np.float64).ravel().copy()
+    # CylindricalMapping2D calls self.arctan2 and raises AttributeError in the reference (texturemap:107)
+    raise NotImplementedError('texture mapping %s is outside the supported hot path' % nm)
+
+
+def texture_record(t):
+    """{'kind', 'mapping', 'm'[16], 'v'[4][3]} of a spectrum texture over constant children
+    (include/pytracer_hip.h pt_texture).  Children are clipped here: util.clip of the selected child
+    (material.py:131) is the selection of the clipped children."""
+    nm = type(t).__name__
+    v = np.zeros((4, 3))
+
+    def child(x):
+        c = _const(x)
+        if c is None:
+            raise NotImplementedError('textures nested in %s must be constant' % nm)
+        return _clip(_spec(c))
+    if nm == 'Chekcerboard2DTexture':
+        kind = A.PT_TEX_CHECKER2D           # 'closedform' == 'none': materials zero the differentials
+        v[0], v[1] = child(t.tex1), child(t.tex2)
+    elif nm == 'Checkboard3DTexture':
+        kind = A.PT_TEX_CHECKER3D
+        v[0], v[1] = child(t.tex1), child(t.tex2)
+    elif nm == 'BilerpTexture':
+        kind = A.PT_TEX_BILERP
+        v[:] = [_spec(t.v00), _spec(t.v01), _spec(t.v10), _spec(t.v11)]
+    elif nm == 'UVTexture':
+        kind = A.PT_TEX_UV
+    else:
+        raise NotImplementedError('texture %s is outside the supported hot path' % nm)
+    mk, m = _mapping_record(t.mapping)
+    if (kind == A.PT_TEX_CHECKER3D) != (mk == A.PT_MAP_IDENTITY3D):
+        raise NotImplementedError('%s needs a %s mapping' % (nm, '3D' if kind == A.PT_TEX_CHECKER3D else '2D'))
+    return dict(kind=int(kind), mapping=int(mk), m=m, v=v)
+
+
+def _tex(t, spectrum=False):
+    """Evaluate a surface-constant texture; with spectrum=True a supported varying texture gives its record."""
+    c = _const(t)
+    if c is not None:
+        return c
+    if spectrum:
+        return texture_record(t)
+    raise NotImplementedError('only constant textures are supported for this parameter, got %s' % type(t).__name__)
 
 
 def material_params(mat):
@@ -117,12 +200,12 @@ def material_params(mat):
     if getattr(mat, 'bump_map', None) is not None:
         raise NotImplementedError('bump mapping is outside the supported hot path')
     if nm == 'MatteMaterial':
-        return 'matte', dict(Kd=_tex(mat.Kd), sigma=_tex(mat.sigma))
+        return 'matte', dict(Kd=_tex(mat.Kd, True), sigma=_tex(mat.sigma))
     if nm == 'UberMaterial':
         return 'uber', dict(Kd=_tex(mat.Kd), Ks=_tex(mat.Ks), Kr=_tex(mat.Kr), Kt=_tex(mat.Kt),
                             roughness=_tex(mat.roughness), opacity=_tex(mat.opacity), eta=_tex(mat.eta))
     if nm == 'PlasticMaterial':
-        return 'plastic', dict(Kd=_tex(mat.Kd), Ks=_tex(mat.Ks), roughness=_tex(mat.roughness))
+        return 'plastic', dict(Kd=_tex(mat.Kd, True), Ks=_tex(mat.Ks, True), roughness=_tex(mat.roughness))
     if nm == 'MirrorMaterial':
         return 'mirror', dict(Kr=_tex(mat.Kr))
     if nm == 'GlassMaterial':
@@ -132,10 +215,14 @@ def material_params(mat):
     raise NotImplementedError('material %s is outside the supported hot path' % nm)
 
 
-def _pack_material(lobes):
+def _pack_material(lobes, textures=None):
+    """pt_material of a lobe list; textured lobes register their record in `textures` (a list)."""
     m = A.pt_material()
     m.n_lobes = len(lobes)
     for i, lobe in enumerate(lobes):
+        extras = lobe[-1] if isinstance(lobe[-1], dict) else None
+        if extras is not None:
+            lobe = lobe[:-1]
         tp, R, a, b, c = lobe[:5]
         m.lobes[i].type = tp
         m.lobes[i].R[:] = [float(x) for x in R]
@@ -143,7 +230,22 @@ def _pack_material(lobes):
         if len(lobe) > 5:
             m.lobes[i].eta[:] = [float(x) for x in lobe[5]]
             m.lobes[i].k[:] = [float(x) for x in lobe[6]]
+        if extras is not None:
+            if textures is None:
+                raise ValueError('textured lobe without a texture table')
+            textures.append(extras['tex'])
+            m.lobes[i].tex = len(textures)
     return m
+
+
+def _pack_texture(rec):
+    t = A.pt_texture()
+    t.kind, t.mapping = int(rec['kind']), int(rec['mapping'])
+    t.m[:] = [float(x) for x in np.asarray(rec['m'], np.float64).ravel()]
+    v = np.asarray(rec['v'], np.float64).reshape(4, 3)
+    for i in range(4):
+        t.v[i][:] = [float(x) for x in v[i]]
+    return t
 
 
 # --------------------------------------------------------------------------------------
@@ -227,8 +329,10 @@ class FlatScene(object):
         if p and (self.tri_mat.min() < 0 or self.tri_mat.max() >= max(1, len(self.material_lobes))):
             raise ValueError('material index out of range')
         self._check_tree()
+        self.textures = []                     # records referenced by textured lobes, in lobe order
         self._materials = (A.pt_material * max(1, len(self.material_lobes)))(
-            *[_pack_material(l) for l in self.material_lobes])
+            *[_pack_material(l, self.textures) for l in self.material_lobes])
+        self._textures = (A.pt_texture * max(1, len(self.textures)))(*[_pack_texture(t) for t in self.textures])
         self._lights = (A.pt_light * max(1, len(self.light_records)))(*[_pack_light(r) for r in self.light_records])
 
     def _check_tree(self):
@@ -277,6 +381,8 @@ class FlatScene(object):
         d.tri_flip = self.tri_flip.ctypes.data
         d.materials = C.cast(self._materials, C.POINTER(A.pt_material))
         d.lights = C.cast(self._lights, C.POINTER(A.pt_light))
+        d.n_textures = len(self.textures)
+        d.textures = C.cast(self._textures, C.POINTER(A.pt_texture))
         return d
 
     def table_dims(self, integ_kind):
@@ -340,6 +446,10 @@ def flat_scene_from_npz(d):
     for i in range(int(d['n_materials'])):
         pre = 'mat%d_' % i
         params = {k[len(pre):]: d[k] for k in d.keys() if k.startswith(pre) and k != pre + 'kind'}
+        # a textured parameter P is stored as P_tex_kind / P_tex_mapping / P_tex_m / P_tex_v
+        for name in [k[:-len('_tex_kind')] for k in list(params) if k.endswith('_tex_kind')]:
+            params[name] = dict(kind=int(params.pop(name + '_tex_kind')), mapping=int(params.pop(name + '_tex_mapping')),
+                                m=params.pop(name + '_tex_m'), v=params.pop(name + '_tex_v'))
         lobes.append(lobes_from_params(_MAT_KINDS[int(d[pre + 'kind'])], **params))
     lights = []
     for i in range(int(d['n_lights'])):

@@ -72,6 +72,16 @@ def tex_value(t):
     return t.value if hasattr(t, 'value') else t(None)
 
 
+def spec_param(t):
+    """A spectrum parameter: the value of a constant texture, or the record of a varying one."""
+    if type(t).__name__ == 'ConstantTexture':
+        return np.array(t.value)
+    sys.path.insert(0, os.path.normpath(os.path.join(HERE, '..', '..')))
+    from pytracer_amd.flatten import _const, texture_record
+    c = _const(t)
+    return np.array(c) if c is not None else texture_record(t)
+
+
 def dump_scene(scene, camera=None):
     agg = scene.aggregate
     N = len(agg.nodes)
@@ -110,7 +120,7 @@ def dump_scene(scene, camera=None):
     for mt in mats:
         nm = type(mt).__name__
         if nm == 'MatteMaterial':
-            mrec.append(dict(kind=0, Kd=np.array(mt.Kd(None)), sigma=float(mt.sigma(None))))
+            mrec.append(dict(kind=0, Kd=spec_param(mt.Kd), sigma=float(mt.sigma(None))))
         elif nm == 'UberMaterial':
             mrec.append(dict(kind=1, Kd=np.array(mt.Kd(None)), Ks=np.array(mt.Ks(None)),
                              Kr=np.array(mt.Kr(None)), Kt=np.array(mt.Kt(None)),
@@ -124,14 +134,18 @@ def dump_scene(scene, camera=None):
         elif nm == 'GlassMaterial':
             mrec.append(dict(kind=4, Kr=np.array(mt.Kr(None)), Kt=np.array(mt.Kt(None)), index=float(mt.index(None))))
         elif nm == 'PlasticMaterial':
-            mrec.append(dict(kind=2, Kd=np.array(mt.Kd(None)), Ks=np.array(mt.Ks(None)),
+            mrec.append(dict(kind=2, Kd=spec_param(mt.Kd), Ks=spec_param(mt.Ks),
                              roughness=float(mt.roughness(None))))
         else:
             raise NotImplementedError(nm)
     d['n_materials'] = np.int32(len(mrec))
     for i, r in enumerate(mrec):
         for k, v in r.items():
-            d['mat%d_%s' % (i, k)] = np.asarray(v)
+            if isinstance(v, dict):            # a non-constant texture: its record (pytracer_amd.flatten.texture_record)
+                for kk, vv in v.items():
+                    d['mat%d_%s_tex_%s' % (i, k, kk)] = np.asarray(vv)
+            else:
+                d['mat%d_%s' % (i, k)] = np.asarray(v)
     # lights
     d['n_lights'] = np.int32(len(scene.lights))
     for i, lt in enumerate(scene.lights):
@@ -486,6 +500,27 @@ class C4Mini(object):
                     GlassMaterial(c3([.8, .8, .8]), c3([.7, .9, .7]), ConstantTexture(1.5)),
                     MatteMaterial(c3([.5, .5, .5]), ConstantTexture(0.))]
             nmesh = 3
+        if variant == 'tex':
+            # §8(f) rank 3, textures: checkerboards (2D closed-form and point-sampled, 3D), bilerp and UV textures
+            # through UV, planar, spherical and 3D identity mappings, in Matte Kd / Plastic Kd and Ks
+            from pytracer.texture.texture import (Chekcerboard2DTexture, Checkboard3DTexture, BilerpTexture, UVTexture,
+                                                  ScaleTexture, MixTexture)
+            from pytracer.texture.texturemap import UVMapping2D, PlannarMapping2D, SphericalMapping2D, IdentityMapping3D
+            c3 = lambda v: ConstantTexture(Spectrum(v))
+            sp = lambda v: Spectrum(v)
+            mats = [MatteMaterial(Chekcerboard2DTexture(UVMapping2D(6., 5., .25, .1), c3([.8, .2, .2]), c3([.1, .1, .7])),
+                                  ConstantTexture(0.)),
+                    PlasticMaterial(Checkboard3DTexture(IdentityMapping3D(Transform.scale(.5, .4, .3)), c3([.2, .6, .3]),
+                                                        ScaleTexture(c3([.9, .9, .2]), ConstantTexture(.5))),
+                                    BilerpTexture(SphericalMapping2D(Transform.translate(geo.Vector(1., -2., 3.))),
+                                                  sp([.1, .1, .1]), sp([.6, .2, .2]), sp([.2, .6, .2]), sp([.3, .3, .7])),
+                                    ConstantTexture(0.05)),
+                    MatteMaterial(UVTexture(UVMapping2D(3., 2., .5, .5)), ConstantTexture(15.)),
+                    MatteMaterial(Chekcerboard2DTexture(PlannarMapping2D(geo.Vector(.25, 0., 0.), geo.Vector(0., .2, 0.), .3, .7),
+                                                        MixTexture(c3([.9, .9, .9]), c3([.5, .5, .5]), ConstantTexture(.25)),
+                                                        c3([.15, .15, .15]), 'none'),
+                                  ConstantTexture(0.))]
+            nmesh = 3
         if variant == 'spec':
             # specular chains: a mirror, glass, and an Uber material with a specular-reflection component
             c3 = lambda v: ConstantTexture(Spectrum(v))
@@ -512,7 +547,7 @@ class C4Mini(object):
         lights = [SpotLight(spot_l2w, Spectrum(200.), 30., 25.),
                   PointLight(Transform.translate(geo.Vector(8., -6., -12.)), Spectrum(150.)),
                   DiffuseAreaLight(st, Spectrum(10.), 2, sph)]
-        if variant in ('spec', 'xtra'):
+        if variant in ('spec', 'xtra', 'tex'):
             lights = lights[1:]
         self.scene = Scene(BVH(prims), lights, None)
 
@@ -819,6 +854,23 @@ def gen_axis():
 
 
 ALL['axis'] = gen_axis
+
+
+def gen_tex():
+    """§8(f) rank 3 (textures): C4Mini('tex') rendered by the reference with Direct (1 spp) and Path (4 spp)."""
+    model = C4Mini('tex')
+    cam = model.configure_camera(x_res=24, y_res=24, file_name='/tmp/_fixture.png')
+    sc = dump_scene(model.scene, cam)
+    for name, integ, xs in (('direct', DirectLightingIntegrator(), 1), ('path', PathIntegrator(max_depth=5), 2)):
+        t = time.time()
+        d = instrumented_render(model, 24, 24, xs, xs, integ, seed=31)
+        d.update(sc)
+        np.savez_compressed(os.path.join(OUT, 'texmini_%s_24x24x%d.npz' % (name, xs * xs)), **d)
+        print('texmini %s: %.1fs, rays logged %d, sumL %.6f, zero-L %d of %d' % (
+            name, time.time() - t, len(d['log_rays']), d['L'].sum(), int((d['L'].sum(1) == 0).sum()), len(d['L'])), flush=True)
+
+
+ALL['tex'] = gen_tex
 
 
 if __name__ == '__main__':
