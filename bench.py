@@ -119,8 +119,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # PT_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
+        # (ranks share devices, the film reduce goes through the host); never used for reported numbers
+        backend = os.environ.get('PT_BENCH_BACKEND', 'nccl')
+        if backend != 'nccl':
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local if world > 1 else 0)
