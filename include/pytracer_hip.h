@@ -53,12 +53,15 @@ typedef enum {
 } pt_lobe_type;
 
 #define PT_MAX_LOBES 5
+#define PT_LOBE_DROP_IF_BLACK 0x10000
 
 typedef struct {
     int32_t type;       /* pt_lobe_type */
-    int32_t tex;        /* 0: R is the lobe's colour; k > 0: colour = R * clip(texture k-1 at the hit)
-                           (pt_scene_desc.textures; Material.get_bsdf evaluates Kd/Ks per hit,
-                           material/material.py:131,175-176) */
+    int32_t tex;        /* 0: R is the lobe's colour.  Low 16 bits k > 0: colour = R * clip(texture k-1 at the
+                           hit) (pt_scene_desc.textures; Material.get_bsdf evaluates its textures per hit,
+                           material/material.py:131,175-176).  PT_LOBE_DROP_IF_BLACK set: the lobe exists at a
+                           hit only if that colour is not black (`if not k.is_black()` of Uber / Mirror /
+                           Glass, material.py:217-219,289-295,343-362; is_black = every component < 1e-5) */
     double R[3];        /* RGB scale (Spectrum = RGBSpectrum, spectral/spectrum.py:610) */
     double a, b, c;
     double eta[3], k[3];/* conductor lobes only */

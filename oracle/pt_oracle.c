@@ -122,7 +122,7 @@ int pto_scene_create(const pt_scene_desc *d, void **out) {
     s->textures = (pt_texture *)dupmem(d->textures, sizeof(pt_texture) * d->n_textures);
     for (int i = 0; i < d->n_materials; i++)
         for (int k = 0; k < s->materials[i].n_lobes; k++)
-            if (s->materials[i].lobes[k].tex < 0 || s->materials[i].lobes[k].tex > d->n_textures) {
+            if (s->materials[i].lobes[k].tex < 0 || (s->materials[i].lobes[k].tex & 0xFFFF) > d->n_textures) {
                 pto_scene_destroy(s);
                 return PT_ERR_ARG;
             }
@@ -329,14 +329,22 @@ static void apply_textures(const oscene *sc, overtex *vx) {
     int any = 0;
     for (int k = 0; k < vx->mat->n_lobes; k++) any |= vx->mat->lobes[k].tex;
     if (!any) return;
-    vx->tmat = *vx->mat;
-    for (int k = 0; k < vx->tmat.n_lobes; k++) {
-        pt_lobe *l = &vx->tmat.lobes[k];
-        if (!l->tex) continue;
-        v3 c = tex_eval(sc->textures + (l->tex - 1), vx);
-        c = V(c.x < 0. ? 0. : c.x, c.y < 0. ? 0. : c.y, c.z < 0. ? 0. : c.z);
-        l->R[0] *= c.x; l->R[1] *= c.y; l->R[2] *= c.z;
+    const pt_material *m = vx->mat;
+    int n = 0;
+    for (int k = 0; k < m->n_lobes; k++) {
+        pt_lobe l = m->lobes[k];
+        const int ti = l.tex & 0xFFFF;
+        if (ti) {
+            v3 c = tex_eval(sc->textures + (ti - 1), vx);
+            c = V(c.x < 0. ? 0. : c.x, c.y < 0. ? 0. : c.y, c.z < 0. ? 0. : c.z);
+            l.R[0] *= c.x; l.R[1] *= c.y; l.R[2] *= c.z;
+            /* `if not k.is_black()`: the lobe is not pushed at this hit (spectrum.py:182-187) */
+            if ((l.tex & PT_LOBE_DROP_IF_BLACK) && l.R[0] < PT_EPS && l.R[1] < PT_EPS && l.R[2] < PT_EPS) continue;
+        }
+        l.tex = 0;
+        vx->tmat.lobes[n++] = l;
     }
+    vx->tmat.n_lobes = n;
     vx->mat = &vx->tmat;
 }
 

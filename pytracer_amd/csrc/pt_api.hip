@@ -255,7 +255,7 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
         if (m.n_lobes < 0 || m.n_lobes > PT_MAX_LOBES) return fail(c, PT_ERR_ARG, "material %d: n_lobes", i);
         for (int k = 0; k < m.n_lobes; k++) {
             if (m.lobes[k].type < 0 || m.lobes[k].type > PT_LOBE_MICROFACET_BLINN_COND) return fail(c, PT_ERR_ARG, "material %d: lobe type", i);
-            if (m.lobes[k].tex < 0 || m.lobes[k].tex > d->n_textures) return fail(c, PT_ERR_ARG, "material %d: texture index", i);
+            if (m.lobes[k].tex < 0 || (m.lobes[k].tex & 0xFFFF) > d->n_textures || (m.lobes[k].tex & ~(0xFFFF | PT_LOBE_DROP_IF_BLACK))) return fail(c, PT_ERR_ARG, "material %d: texture index", i);
             spec |= m.lobes[k].type == PT_LOBE_SPEC_REFLECT;
         }
     }

@@ -213,15 +213,20 @@ __device__ inline void apply_textures(const DScene &sc, Vertex &vx, double b1, d
     // Triangle.intersect, triangle.py:228-231 with the default uvs (0,0),(1,0),(1,1)
     const double b0 = 1.0 - b1 - b2;
     const double u = (b0 * 0. + b1 * 1.) + b2 * 1., v = (b0 * 0. + b1 * 0.) + b2 * 1.;
-    *scratch = m;
+    int n = 0;
     for (int k = 0; k < m.n_lobes; k++) {
-        const int ti = m.lobes[k].tex;
-        if (!ti) continue;
-        d3 c = tex_eval(sc.textures[ti - 1], vx.p, u, v);
-        scratch->lobes[k].R[0] = m.lobes[k].R[0] * max0(c.x);
-        scratch->lobes[k].R[1] = m.lobes[k].R[1] * max0(c.y);
-        scratch->lobes[k].R[2] = m.lobes[k].R[2] * max0(c.z);
+        pt_lobe l = m.lobes[k];
+        const int ti = l.tex & 0xFFFF;
+        if (ti) {
+            d3 c = tex_eval(sc.textures[ti - 1], vx.p, u, v);
+            l.R[0] *= max0(c.x); l.R[1] *= max0(c.y); l.R[2] *= max0(c.z);
+            // `if not k.is_black()` (material.py:217-219,289-295,343-362): the lobe is not pushed at this hit
+            if ((l.tex & PT_LOBE_DROP_IF_BLACK) && l.R[0] < PT_EPS && l.R[1] < PT_EPS && l.R[2] < PT_EPS) continue;
+        }
+        l.tex = 0;
+        scratch->lobes[n++] = l;
     }
+    scratch->n_lobes = n;
     vx.mat = scratch;
 }
 

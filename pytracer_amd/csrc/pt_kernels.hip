@@ -450,15 +450,17 @@ size_t pt_trace_meta_lds(int stack, int n_nodes) {
 hipError_t pt_launch_trace_meta(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
                                 long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                                 double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
-    static bool attr_set[2] = {false, false};
+    static bool attr_set[PT_MAX_DEVICES][2];
     const size_t lds = pt_trace_meta_lds(stack, sc.n_nodes);
-    if (!attr_set[any ? 1 : 0]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!attr_set[dev][any ? 1 : 0]) {
         hipError_t e = any ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_meta<true>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
                            : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_meta<false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[any ? 1 : 0] = true;
+        attr_set[dev][any ? 1 : 0] = true;
     }
     if (seg_counts) {   // whole sets of PT_SEG waves
         const int per = PT_SEG / (PT_TOP_BLOCK / 64);
@@ -481,15 +483,19 @@ size_t pt_trace_top_lds(int stack, int n_top) {
 hipError_t pt_launch_trace_top(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
                                long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                                double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
-    static bool attr_set[2] = {false, false};
+    // the attribute belongs to the function ON THE CURRENT DEVICE: remember it per device (one process may
+    // drive a context on each of the node's GPUs)
+    static bool attr_set[PT_MAX_DEVICES][2];
     const size_t lds = pt_trace_top_lds(stack, sc.n_top);
-    if (!attr_set[any ? 1 : 0]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!attr_set[dev][any ? 1 : 0]) {
         hipError_t e = any ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_top<true>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
                            : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_top<false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[any ? 1 : 0] = true;
+        attr_set[dev][any ? 1 : 0] = true;
     }
     if (seg_counts) {   // whole sets of PT_SEG waves
         const int per = PT_SEG / (PT_TOP_BLOCK / 64);

@@ -10,8 +10,9 @@ exist — gets its scenes.
 Materials are evaluated at flatten time into the ordered lobe list ``Material.get_bsdf`` would push
 (reference pytracer/material/material.py:122-141, 166-189, 208-222, 280-299, 329-364).  Parameters are
 ConstantTextures (or Scale/Mix of constants, folded here); the spectrum parameters whose lobe is pushed
-unconditionally — Matte Kd, Plastic Kd and Ks — may also be a checkerboard / bilerp / UV texture
-(``texture_record``), evaluated per hit on the device.
+of Matte (Kd), Plastic (Kd, Ks), Uber (Kd, Ks, Kr, Kt), Mirror (Kr) and Glass (Kr, Kt) may also be a
+checkerboard / bilerp / UV texture (``texture_record``), evaluated per hit on the device — including the
+``is_black`` tests with which Uber / Mirror / Glass decide per hit whether a lobe exists.
 """
 import ctypes as C
 
@@ -45,12 +46,17 @@ def _blinn_exponent(rough):
     return float(np.clip(1. / rough, -np.inf, 10000.))
 
 
-def _colour(v):
-    """(R, extras) of a spectrum parameter: a constant is clipped here; a texture record (dict, see
-    texture_record) leaves R = 1 and rides along as the lobe's last tuple element {'tex': record}."""
+def _colour(v, scale=None, drop=False):
+    """(R, extras, exists) of a spectrum parameter.  A constant is clipped (and scaled) here and `exists` is the
+    material's own is_black test when `drop`.  A texture record (dict, see texture_record) leaves R = scale (or 1)
+    and rides along as the lobe's last tuple element {'tex': record, 'drop': bool}: the colour, and with `drop`
+    the lobe's existence, are decided per hit on the device."""
     if isinstance(v, dict):
-        return np.ones(3), ({'tex': v},)
-    return _clip(_spec(v)), ()
+        return (np.ones(3) if scale is None else np.asarray(scale, np.float64)), ({'tex': v, 'drop': bool(drop)},), True
+    r = _clip(_spec(v))
+    if scale is not None:
+        r = np.asarray(scale, np.float64) * r
+    return r, (), (not drop) or (not _is_black(r))
 
 
 def lobes_from_params(kind, **p):
@@ -60,12 +66,14 @@ def lobes_from_params(kind, **p):
     (a conductor lobe carries two more entries: eta[3], k[3]; a textured lobe ends with {'tex': record})
     """
     out = []
+    textured_ok = {'matte': ('Kd',), 'plastic': ('Kd', 'Ks'), 'uber': ('Kd', 'Ks', 'Kr', 'Kt'), 'mirror': ('Kr',),
+                   'glass': ('Kr', 'Kt')}
     for name, v in p.items():
-        if isinstance(v, dict) and not (kind == 'matte' and name == 'Kd') and not (kind == 'plastic' and name in ('Kd', 'Ks')):
-            raise NotImplementedError('a non-constant texture is supported for Matte Kd and Plastic Kd / Ks only '
-                                      '(%s %s decides per hit which lobes exist)' % (kind, name))
+        if isinstance(v, dict) and name not in textured_ok.get(kind, ()):
+            raise NotImplementedError('a non-constant texture is supported for the colours %s of %s only, not for %s'
+                                      % ('/'.join(textured_ok.get(kind, ())) or '(none)', kind, name))
     if kind == 'matte':                         # material.py:122-141
-        r, ex = _colour(p['Kd'])
+        r, ex, _ = _colour(p['Kd'])
         sigma = float(np.clip(p['sigma'], 0., 90.))
         if sigma == 0.:
             out.append((A.PT_LOBE_LAMBERT, r, 0., 0., 0.) + ex)
@@ -79,36 +87,36 @@ def lobes_from_params(kind, **p):
         op = _clip(_spec(p['opacity']))
         if not np.array_equal(op, [1., 1., 1.]):
             out.append((A.PT_LOBE_SPEC_TRANSMIT, 1. - op, 1., 1., 0.))
-        kd = op * _clip(_spec(p['Kd']))
-        if not _is_black(kd):
-            out.append((A.PT_LOBE_LAMBERT, kd, 0., 0., 0.))
         e = float(p['eta'])
-        ks = op * _clip(_spec(p['Ks']))
-        if not _is_black(ks):
-            out.append((A.PT_LOBE_MICROFACET_BLINN, ks, e, 1., _blinn_exponent(float(p['roughness']))))
-        kr = op * _clip(_spec(p['Kr']))
-        if not _is_black(kr):
-            out.append((A.PT_LOBE_SPEC_REFLECT, kr, e, 1., 0.))
-        kt = op * _clip(_spec(p['Kt']))
-        if not _is_black(kt):
-            out.append((A.PT_LOBE_SPEC_TRANSMIT, kt, e, 1., 0.))
+        kd, ex, on = _colour(p['Kd'], op, True)
+        if on:
+            out.append((A.PT_LOBE_LAMBERT, kd, 0., 0., 0.) + ex)
+        ks, ex, on = _colour(p['Ks'], op, True)
+        if on:
+            out.append((A.PT_LOBE_MICROFACET_BLINN, ks, e, 1., _blinn_exponent(float(p['roughness']))) + ex)
+        kr, ex, on = _colour(p['Kr'], op, True)
+        if on:
+            out.append((A.PT_LOBE_SPEC_REFLECT, kr, e, 1., 0.) + ex)
+        kt, ex, on = _colour(p['Kt'], op, True)
+        if on:
+            out.append((A.PT_LOBE_SPEC_TRANSMIT, kt, e, 1., 0.) + ex)
     elif kind == 'plastic':                     # material.py:166-189
-        kd, exd = _colour(p['Kd'])
-        ks, exs = _colour(p['Ks'])
+        kd, exd, _ = _colour(p['Kd'])
+        ks, exs, _ = _colour(p['Ks'])
         out.append((A.PT_LOBE_LAMBERT, kd, 0., 0., 0.) + exd)
         out.append((A.PT_LOBE_MICROFACET_BLINN, ks, 1.5, 1., _blinn_exponent(float(p['roughness']))) + exs)
     elif kind == 'mirror':                      # material.py:208-222
-        r = _clip(_spec(p['Kr']))
-        if not _is_black(r):
-            out.append((A.PT_LOBE_SPEC_REFLECT, r, 1., 1., 1.))      # c != 0: FresnelFullReflect
+        r, ex, on = _colour(p['Kr'], None, True)
+        if on:
+            out.append((A.PT_LOBE_SPEC_REFLECT, r, 1., 1., 1.) + ex)      # c != 0: FresnelFullReflect
     elif kind == 'glass':                       # material.py:280-299
         ior = float(p['index'])
-        r = _clip(_spec(p['Kr']))
-        if not _is_black(r):
-            out.append((A.PT_LOBE_SPEC_REFLECT, r, 1., ior, 0.))
-        t = _clip(_spec(p['Kt']))
-        if not _is_black(t):
-            out.append((A.PT_LOBE_SPEC_TRANSMIT, t, 1., ior, 0.))
+        r, ex, on = _colour(p['Kr'], None, True)
+        if on:
+            out.append((A.PT_LOBE_SPEC_REFLECT, r, 1., ior, 0.) + ex)
+        t, ex, on = _colour(p['Kt'], None, True)
+        if on:
+            out.append((A.PT_LOBE_SPEC_TRANSMIT, t, 1., ior, 0.) + ex)
     elif kind == 'metal':                       # material.py:242-258: Microfacet(Spectrum(1.), FresnelConductor, Blinn)
         out.append((A.PT_LOBE_MICROFACET_BLINN_COND, np.ones(3), 0., 0., _blinn_exponent(float(p['roughness'])),
                     _spec(p['eta']), _spec(p['k'])))
@@ -202,14 +210,14 @@ def material_params(mat):
     if nm == 'MatteMaterial':
         return 'matte', dict(Kd=_tex(mat.Kd, True), sigma=_tex(mat.sigma))
     if nm == 'UberMaterial':
-        return 'uber', dict(Kd=_tex(mat.Kd), Ks=_tex(mat.Ks), Kr=_tex(mat.Kr), Kt=_tex(mat.Kt),
+        return 'uber', dict(Kd=_tex(mat.Kd, True), Ks=_tex(mat.Ks, True), Kr=_tex(mat.Kr, True), Kt=_tex(mat.Kt, True),
                             roughness=_tex(mat.roughness), opacity=_tex(mat.opacity), eta=_tex(mat.eta))
     if nm == 'PlasticMaterial':
         return 'plastic', dict(Kd=_tex(mat.Kd, True), Ks=_tex(mat.Ks, True), roughness=_tex(mat.roughness))
     if nm == 'MirrorMaterial':
-        return 'mirror', dict(Kr=_tex(mat.Kr))
+        return 'mirror', dict(Kr=_tex(mat.Kr, True))
     if nm == 'GlassMaterial':
-        return 'glass', dict(Kr=_tex(mat.Kr), Kt=_tex(mat.Kt), index=_tex(mat.index))
+        return 'glass', dict(Kr=_tex(mat.Kr, True), Kt=_tex(mat.Kt, True), index=_tex(mat.index))
     if nm == 'MetalMaterial':
         return 'metal', dict(eta=_tex(mat.eta), k=_tex(mat.k), roughness=_tex(mat.roughness))
     raise NotImplementedError('material %s is outside the supported hot path' % nm)
@@ -234,7 +242,7 @@ def _pack_material(lobes, textures=None):
             if textures is None:
                 raise ValueError('textured lobe without a texture table')
             textures.append(extras['tex'])
-            m.lobes[i].tex = len(textures)
+            m.lobes[i].tex = len(textures) | (A.PT_LOBE_DROP_IF_BLACK if extras.get('drop') else 0)
     return m
 
 

@@ -122,17 +122,17 @@ def dump_scene(scene, camera=None):
         if nm == 'MatteMaterial':
             mrec.append(dict(kind=0, Kd=spec_param(mt.Kd), sigma=float(mt.sigma(None))))
         elif nm == 'UberMaterial':
-            mrec.append(dict(kind=1, Kd=np.array(mt.Kd(None)), Ks=np.array(mt.Ks(None)),
-                             Kr=np.array(mt.Kr(None)), Kt=np.array(mt.Kt(None)),
+            mrec.append(dict(kind=1, Kd=spec_param(mt.Kd), Ks=spec_param(mt.Ks),
+                             Kr=spec_param(mt.Kr), Kt=spec_param(mt.Kt),
                              roughness=float(mt.roughness(None)), opacity=np.array(mt.opacity(None)),
                              eta=float(mt.eta(None))))
         elif nm == 'MetalMaterial':
             mrec.append(dict(kind=5, eta=np.array(mt.eta(None)), k=np.array(mt.k(None)),
                              roughness=float(mt.roughness(None))))
         elif nm == 'MirrorMaterial':
-            mrec.append(dict(kind=3, Kr=np.array(mt.Kr(None))))
+            mrec.append(dict(kind=3, Kr=spec_param(mt.Kr)))
         elif nm == 'GlassMaterial':
-            mrec.append(dict(kind=4, Kr=np.array(mt.Kr(None)), Kt=np.array(mt.Kt(None)), index=float(mt.index(None))))
+            mrec.append(dict(kind=4, Kr=spec_param(mt.Kr), Kt=spec_param(mt.Kt), index=float(mt.index(None))))
         elif nm == 'PlasticMaterial':
             mrec.append(dict(kind=2, Kd=spec_param(mt.Kd), Ks=spec_param(mt.Ks),
                              roughness=float(mt.roughness(None))))
@@ -521,6 +521,24 @@ class C4Mini(object):
                                                         c3([.15, .15, .15]), 'none'),
                                   ConstantTexture(0.))]
             nmesh = 3
+        if variant == 'tex2':
+            # textured colours of the materials that decide PER HIT which lobes exist (`if not k.is_black()`):
+            # a mirror whose Kr checkerboard has black checks (no lobe there), glass with a textured Kt,
+            # an Uber material with opacity < 1 and checkerboards in Kd (one check black) and Kr
+            from pytracer.texture.texture import Chekcerboard2DTexture, Checkboard3DTexture, UVTexture
+            from pytracer.texture.texturemap import UVMapping2D, PlannarMapping2D, IdentityMapping3D
+            c3 = lambda v: ConstantTexture(Spectrum(v))
+            mats = [MirrorMaterial(Chekcerboard2DTexture(UVMapping2D(4., 4., 0., 0.), c3([.9, .8, .7]), c3([0., 0., 0.]))),
+                    GlassMaterial(c3([.8, .8, .8]),
+                                  Checkboard3DTexture(IdentityMapping3D(Transform.scale(.4, .4, .4)), c3([.7, .9, .7]),
+                                                      c3([0., 0., 0.])), ConstantTexture(1.5)),
+                    UberMaterial(Chekcerboard2DTexture(UVMapping2D(3., 3., .5, 0.), c3([.6, .4, .2]), c3([0., 0., 0.]), 'none'),
+                                 c3([.2, .2, .2]),
+                                 Chekcerboard2DTexture(PlannarMapping2D(geo.Vector(.5, 0., 0.), geo.Vector(0., .5, 0.), 0., 0.),
+                                                       c3([.5, .5, .5]), c3([0., 0., 0.])),
+                                 c3([0., 0., 0.]), ConstantTexture(.2), c3([.8, .8, .8]), ConstantTexture(1.33)),
+                    MatteMaterial(c3([.5, .5, .5]), ConstantTexture(0.))]
+            nmesh = 3
         if variant == 'spec':
             # specular chains: a mirror, glass, and an Uber material with a specular-reflection component
             c3 = lambda v: ConstantTexture(Spectrum(v))
@@ -547,7 +565,7 @@ class C4Mini(object):
         lights = [SpotLight(spot_l2w, Spectrum(200.), 30., 25.),
                   PointLight(Transform.translate(geo.Vector(8., -6., -12.)), Spectrum(150.)),
                   DiffuseAreaLight(st, Spectrum(10.), 2, sph)]
-        if variant in ('spec', 'xtra', 'tex'):
+        if variant in ('spec', 'xtra', 'tex', 'tex2'):
             lights = lights[1:]
         self.scene = Scene(BVH(prims), lights, None)
 
@@ -871,6 +889,24 @@ def gen_tex():
 
 
 ALL['tex'] = gen_tex
+
+
+def gen_tex2():
+    """Textured Mirror / Glass / Uber colours (per-hit lobe existence) under Direct, Path and Whitted."""
+    model = C4Mini('tex2')
+    cam = model.configure_camera(x_res=24, y_res=24, file_name='/tmp/_fixture.png')
+    sc = dump_scene(model.scene, cam)
+    for name, integ, xs in (('direct', DirectLightingIntegrator(), 1), ('path', PathIntegrator(max_depth=5), 2),
+                            ('whitted', WhittedIntegrator(), 1)):
+        t = time.time()
+        d = instrumented_render(model, 24, 24, xs, xs, integ, seed=41)
+        d.update(sc)
+        np.savez_compressed(os.path.join(OUT, 'tex2mini_%s_24x24x%d.npz' % (name, xs * xs)), **d)
+        print('tex2mini %s: %.1fs, rays logged %d, sumL %.6f, zero-L %d of %d' % (
+            name, time.time() - t, len(d['log_rays']), d['L'].sum(), int((d['L'].sum(1) == 0).sum()), len(d['L'])), flush=True)
+
+
+ALL['tex2'] = gen_tex2
 
 
 if __name__ == '__main__':
