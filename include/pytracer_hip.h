@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 7
+#define PT_ABI_VERSION 8
 
 typedef enum {
     PT_OK = 0,
@@ -132,6 +132,9 @@ typedef struct {
     const pt_light *lights;      /* host [n_lights] */
     int32_t n_textures, _pad;
     const pt_texture *textures;  /* host [n_textures]; referenced by pt_lobe.tex */
+    const double *tri_uv;        /* host [n_tris][6] or NULL: (u,v) of the triangle's three corners as
+                                    Triangle.get_uvs returns them (shape/triangle.py:125-131; NULL = the
+                                    default (0,0),(1,0),(1,1) for every triangle) */
 } pt_scene_desc;
 
 /* ---- camera (camera/projective.py:42-59; OrthoCamera :65-127; PerspectiveCamera

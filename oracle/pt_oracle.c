@@ -96,6 +96,7 @@ typedef struct {
     pt_light *lights;
     int32_t n_textures;
     pt_texture *textures;
+    double *tri_uv;        /* [n_tris][6] or NULL */
 } oscene;
 
 static void *dupmem(const void *p, size_t n) {
@@ -120,6 +121,7 @@ int pto_scene_create(const pt_scene_desc *d, void **out) {
     s->lights = (pt_light *)dupmem(d->lights, sizeof(pt_light) * d->n_lights);
     s->n_textures = d->n_textures;
     s->textures = (pt_texture *)dupmem(d->textures, sizeof(pt_texture) * d->n_textures);
+    s->tri_uv = d->tri_uv ? (double *)dupmem(d->tri_uv, sizeof(double) * 6 * d->n_tris) : NULL;
     for (int i = 0; i < d->n_materials; i++)
         for (int k = 0; k < s->materials[i].n_lobes; k++)
             if (s->materials[i].lobes[k].tex < 0 || (s->materials[i].lobes[k].tex & 0xFFFF) > d->n_textures) {
@@ -134,7 +136,7 @@ int pto_scene_destroy(void *p) {
     oscene *s = (oscene *)p;
     if (!s) return PT_OK;
     free(s->node_bounds); free(s->node_meta); free(s->tri_verts); free(s->tri_mat);
-    free(s->tri_flip); free(s->materials); free(s->lights); free(s->textures); free(s);
+    free(s->tri_flip); free(s->materials); free(s->lights); free(s->textures); free(s->tri_uv); free(s);
     return PT_OK;
 }
 
@@ -356,13 +358,35 @@ static void apply_textures(const oscene *sc, overtex *vx) {
 static void make_vertex(const oscene *s, const oray *r, const ohit *h, overtex *vx) {
     const double *tv = s->tri_verts + 9 * h->prim;
     v3 p1 = V(tv[0], tv[1], tv[2]), p2 = V(tv[3], tv[4], tv[5]), p3 = V(tv[6], tv[7], tv[8]);
-    const double uv00 = 0., uv01 = 0., uv10 = 1., uv11 = 0., uv20 = 1., uv21 = 1.;
+    double uv00 = 0., uv01 = 0., uv10 = 1., uv11 = 0., uv20 = 1., uv21 = 1.;      /* triangle.py:125-131 */
+    if (s->tri_uv) {
+        const double *q = s->tri_uv + 6 * (size_t)h->prim;
+        uv00 = q[0]; uv01 = q[1]; uv10 = q[2]; uv11 = q[3]; uv20 = q[4]; uv21 = q[5];
+    }
     double du1 = uv00 - uv20, du2 = uv10 - uv20, dv1 = uv01 - uv21, dv2 = uv11 - uv21;
     v3 dp1 = vsub(p1, p3), dp2 = vsub(p2, p3);
     double det = du1 * dv2 - du2 * dv1;       /* == 1 for the default uvs */
-    double detInv = 1.0 / det;
-    vx->dpdu = vmul(vsub(vmul(dp1, dv2), vmul(dp2, dv1)), detInv);
-    vx->dpdv = vmul(vadd(vmul(dp1, -du2), vmul(dp2, du1)), detInv);
+    if (det == 0.) {
+        /* triangle.py:219-221: _, dpdu, dpdv = coordinate_system(normalize(e2 x e1)), geometry/utility.py:40-52 */
+        v3 v1 = vnormalize(vcross(vsub(p3, p1), vsub(p2, p1)));
+        v3 v2;
+        if (vlen(v1) == 0.) { vx->dpdu = V(0., 1., 0.); vx->dpdv = V(0., 0., 1.); }
+        else {
+            if (fabs(v1.x) > fabs(v1.y)) {
+                double inv_len = 1. / sqrt(v1.x * v1.x + v1.z * v1.z);
+                v2 = V(-v1.z * inv_len, 0., v1.x * inv_len);
+            } else {
+                double inv_len = 1. / sqrt(v1.y * v1.y + v1.z * v1.z);
+                v2 = V(0., -v1.z * inv_len, v1.y * inv_len);
+            }
+            vx->dpdu = v2;
+            vx->dpdv = vcross(v1, v2);
+        }
+    } else {
+        double detInv = 1.0 / det;
+        vx->dpdu = vmul(vsub(vmul(dp1, dv2), vmul(dp2, dv1)), detInv);
+        vx->dpdv = vmul(vadd(vmul(dp1, -du2), vmul(dp2, du1)), detInv);
+    }
     double b0 = 1.0 - h->b1 - h->b2;
     vx->u = b0 * uv00 + h->b1 * uv10 + h->b2 * uv20;
     vx->v = b0 * uv01 + h->b1 * uv11 + h->b2 * uv21;

@@ -1,7 +1,7 @@
 """ctypes mirror of include/pytracer_hip.h (struct layouts and enums only)."""
 import ctypes as C
 
-PT_ABI_VERSION = 7
+PT_ABI_VERSION = 8
 PT_MAX_LOBES = 5
 
 PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
@@ -43,7 +43,8 @@ class pt_scene_desc(C.Structure):
                 ('node_bounds', C.c_void_p), ('node_meta', C.c_void_p), ('tri_verts', C.c_void_p),
                 ('tri_mat', C.c_void_p), ('tri_flip', C.c_void_p),
                 ('materials', C.POINTER(pt_material)), ('lights', C.POINTER(pt_light)),
-                ('n_textures', C.c_int32), ('_pad', C.c_int32), ('textures', C.POINTER(pt_texture))]
+                ('n_textures', C.c_int32), ('_pad', C.c_int32), ('textures', C.POINTER(pt_texture)),
+                ('tri_uv', C.c_void_p)]
 
 
 class pt_camera(C.Structure):

@@ -17,7 +17,7 @@ struct pt_ctx {
     // scene (device)
     bool have_scene;
     DScene sc;
-    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch;
+    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv;
     int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
     int meta_stack;          // todo levels of k_trace_meta's LDS stacks (0: the tree's child words do not fit in LDS)
     int use_meta;            // k_trace_meta when the tree fits: PT_TRACE_META=0 never, 1 (default) closest-hit launches
@@ -163,7 +163,7 @@ static void collect_timing(pt_ctx *c, pt_stats *stats) {
 
 static void free_scene(pt_ctx *c) {
     void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top,
-                   &c->d_tex, &c->d_tex_scratch};
+                   &c->d_tex, &c->d_tex_scratch, &c->d_uv};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -350,6 +350,7 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
         const size_t threads = ((size_t)c->n_cu * 4 + PT_SEG_BLOCKS) * PT_BLOCK;
         HIPCHK(c, hipMalloc(&c->d_tex_scratch, threads * sizeof(pt_material)));
     }
+    if (d->tri_uv && d->n_tris > 0) HIPCHK(c, upload(&c->d_uv, d->tri_uv, 6 * (size_t)d->n_tris));
     DScene &s = c->sc;
     s.nodes = (const GNode *)c->d_nodes;
     s.top = n_top ? (const TopNode *)c->d_top : nullptr;
@@ -367,6 +368,7 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     s.lights = (const pt_light *)c->d_lights;
     s.textures = (const pt_texture *)c->d_tex;
     s.tex_scratch = (pt_material *)c->d_tex_scratch;
+    s.tri_uv = (const double *)c->d_uv;
     s.n_nodes = d->n_nodes; s.n_tris = d->n_tris; s.n_mats = d->n_materials; s.n_lights = d->n_lights;
     memcpy(s.le_sum, le, sizeof(le));
     c->stack_need = std::max(depth, 1);

@@ -109,6 +109,7 @@ struct DScene {
     const pt_light *lights;
     const pt_texture *textures;   // referenced by pt_lobe.tex (k > 0: textures[k-1])
     pt_material *tex_scratch;     // one pt_material per shading thread: the textured material at its vertex
+    const double *tri_uv;         // [n_tris][6] corner (u,v) of meshes with uvs, or nullptr (triangle.py:125-131)
     int32_t n_nodes, n_tris, n_mats, n_lights;
     double le_sum[3];          // Σ light.le over lights (DiffuseAreaLight.le = emit, light.py:503-505)
 };
@@ -129,15 +130,44 @@ struct Vertex {
     const pt_material *mat;
 };
 
+// EXT: the scene has textures or mesh uvs (k_shade<KIND, true>); without it the default uvs are compile-time constants
+template <bool EXT>
 __device__ inline void make_vertex(const DScene &sc, const Ray &r, int prim, double t, Vertex &vx) {
     const double *tv = sc.tri_verts + 9 * (size_t)prim;
     d3 p1 = mk3(tv[0], tv[1], tv[2]), p2 = mk3(tv[3], tv[4], tv[5]), p3 = mk3(tv[6], tv[7], tv[8]);
-    const double du1 = 0. - 1., du2 = 1. - 1., dv1 = 0. - 1., dv2 = 0. - 1.;
-    d3 dp1 = p1 - p3, dp2 = p2 - p3;
-    double det = du1 * dv2 - du2 * dv1;
-    double detInv = 1.0 / det;
-    d3 dpdu = ((dp1 * dv2) - (dp2 * dv1)) * detInv;
-    d3 dpdv = ((dp1 * (-du2)) + (dp2 * du1)) * detInv;
+    d3 dpdu, dpdv;
+    if (EXT && sc.tri_uv) {
+        const double *q = sc.tri_uv + 6 * (size_t)prim;
+        const double du1 = q[0] - q[4], du2 = q[2] - q[4], dv1 = q[1] - q[5], dv2 = q[3] - q[5];
+        d3 dp1 = p1 - p3, dp2 = p2 - p3;
+        const double det = du1 * dv2 - du2 * dv1;
+        if (det == 0.) {
+            // triangle.py:219-221: _, dpdu, dpdv = coordinate_system(normalize(e2 x e1)), geometry/utility.py:40-52
+            d3 v1 = normalize3(cross3(p3 - p1, p2 - p1));
+            if (sqrt(dot3(v1, v1)) == 0.) { dpdu = mk3(0., 1., 0.); dpdv = mk3(0., 0., 1.); }
+            else {
+                if (fabs(v1.x) > fabs(v1.y)) {
+                    const double inv_len = 1. / sqrt(v1.x * v1.x + v1.z * v1.z);
+                    dpdu = mk3(-v1.z * inv_len, 0., v1.x * inv_len);
+                } else {
+                    const double inv_len = 1. / sqrt(v1.y * v1.y + v1.z * v1.z);
+                    dpdu = mk3(0., -v1.z * inv_len, v1.y * inv_len);
+                }
+                dpdv = cross3(v1, dpdu);
+            }
+        } else {
+            const double detInv = 1.0 / det;
+            dpdu = ((dp1 * dv2) - (dp2 * dv1)) * detInv;
+            dpdv = ((dp1 * (-du2)) + (dp2 * du1)) * detInv;
+        }
+    } else {
+        const double du1 = 0. - 1., du2 = 1. - 1., dv1 = 0. - 1., dv2 = 0. - 1.;
+        d3 dp1 = p1 - p3, dp2 = p2 - p3;
+        double det = du1 * dv2 - du2 * dv1;
+        double detInv = 1.0 / det;
+        dpdu = ((dp1 * dv2) - (dp2 * dv1)) * detInv;
+        dpdv = ((dp1 * (-du2)) + (dp2 * du1)) * detInv;
+    }
     vx.p = r.o + r.d * t;
     vx.nn = normalize3(cross3(dpdu, dpdv));
     if (sc.tri_flip[prim]) vx.nn = vx.nn * -1.0;
@@ -205,14 +235,19 @@ __device__ inline d3 tex_eval(const pt_texture &t, d3 p, double u, double v) {
 // A material with textured lobes is evaluated ONCE per vertex into the calling thread's scratch record
 // (lobe colour = R * util.clip(texture(dgs)), material.py:131) and the vertex points at that copy: the BSDF code
 // reads lobes through vx.mat and never knows.  Materials without textures (tex == 0 in every lobe) pay one test.
-__device__ inline void apply_textures(const DScene &sc, Vertex &vx, double b1, double b2, pt_material *scratch) {
+__device__ inline void apply_textures(const DScene &sc, Vertex &vx, int prim, double b1, double b2, pt_material *scratch) {
     const pt_material &m = *vx.mat;
     int any = 0;
     for (int k = 0; k < m.n_lobes; k++) any |= m.lobes[k].tex;
     if (!any) return;
     // Triangle.intersect, triangle.py:228-231 with the default uvs (0,0),(1,0),(1,1)
     const double b0 = 1.0 - b1 - b2;
-    const double u = (b0 * 0. + b1 * 1.) + b2 * 1., v = (b0 * 0. + b1 * 0.) + b2 * 1.;
+    double u = (b0 * 0. + b1 * 1.) + b2 * 1., v = (b0 * 0. + b1 * 0.) + b2 * 1.;
+    if (sc.tri_uv) {
+        const double *q = sc.tri_uv + 6 * (size_t)prim;
+        u = (b0 * q[0] + b1 * q[2]) + b2 * q[4];
+        v = (b0 * q[1] + b1 * q[3]) + b2 * q[5];
+    }
     int n = 0;
     for (int k = 0; k < m.n_lobes; k++) {
         pt_lobe l = m.lobes[k];

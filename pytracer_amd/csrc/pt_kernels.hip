@@ -824,9 +824,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
         if (hit) {
             ray.o = mk3(qin.rays[i], qin.rays[S + i], qin.rays[2 * S + i]);
             ray.d = mk3(qin.rays[3 * S + i], qin.rays[4 * S + i], qin.rays[5 * S + i]);
-            make_vertex(sc, ray, prim, qin.t[i], vx);
-            if (TEX)
-                apply_textures(sc, vx, qin.b1[i], qin.b2[i], sc.tex_scratch + ((size_t)blockIdx.x * PT_BLOCK + threadIdx.x));
+            make_vertex<TEX>(sc, ray, prim, qin.t[i], vx);
+            if (TEX && sc.textures)
+                apply_textures(sc, vx, prim, qin.b1[i], qin.b2[i], sc.tex_scratch + ((size_t)blockIdx.x * PT_BLOCK + threadIdx.x));
             wo = -ray.d;
             int px, py, si;
             uint32_t sid;
@@ -998,7 +998,7 @@ hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene 
                            const PathState &st) {
     grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
 #define PT_SHADE(K, T) hipLaunchKernelGGL((k_shade<K, T>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st)
-    const bool tex = sc.textures != nullptr;
+    const bool tex = sc.textures != nullptr || sc.tri_uv != nullptr;
     if (kind == PT_INTEG_DIRECT) { if (tex) PT_SHADE(PT_INTEG_DIRECT, true); else PT_SHADE(PT_INTEG_DIRECT, false); }
     else if (kind == PT_INTEG_WHITTED) { if (tex) PT_SHADE(PT_INTEG_WHITTED, true); else PT_SHADE(PT_INTEG_WHITTED, false); }
     else { if (tex) PT_SHADE(PT_INTEG_PATH, true); else PT_SHADE(PT_INTEG_PATH, false); }

@@ -323,16 +323,19 @@ def light_record(light):
 class FlatScene(object):
     """Arrays of one scene in the layout pt_scene_desc points at (all host memory)."""
 
-    def __init__(self, node_bounds, node_meta, tri_verts, tri_mat, tri_flip, material_lobes, light_records):
+    def __init__(self, node_bounds, node_meta, tri_verts, tri_mat, tri_flip, material_lobes, light_records, tri_uv=None):
         self.node_bounds = np.ascontiguousarray(node_bounds, np.float64).reshape(-1, 6)
         self.node_meta = np.ascontiguousarray(node_meta, np.int32).reshape(-1, 3)
         self.tri_verts = np.ascontiguousarray(tri_verts, np.float64).reshape(-1, 9)
         self.tri_mat = np.ascontiguousarray(tri_mat, np.int32).ravel()
         self.tri_flip = np.ascontiguousarray(tri_flip, np.int32).ravel()
+        # corner (u,v) per triangle as Triangle.get_uvs returns them, or None for the defaults (triangle.py:125-131)
+        self.tri_uv = None if tri_uv is None else np.ascontiguousarray(tri_uv, np.float64).reshape(-1, 6)
         self.material_lobes = list(material_lobes)
         self.light_records = list(light_records)
         n, p = len(self.node_bounds), len(self.tri_verts)
-        if len(self.node_meta) != n or len(self.tri_mat) != p or len(self.tri_flip) != p:
+        if len(self.node_meta) != n or len(self.tri_mat) != p or len(self.tri_flip) != p or \
+                (self.tri_uv is not None and len(self.tri_uv) != p):
             raise ValueError('inconsistent scene array lengths')
         if p and (self.tri_mat.min() < 0 or self.tri_mat.max() >= max(1, len(self.material_lobes))):
             raise ValueError('material index out of range')
@@ -391,6 +394,7 @@ class FlatScene(object):
         d.lights = C.cast(self._lights, C.POINTER(A.pt_light))
         d.n_textures = len(self.textures)
         d.textures = C.cast(self._textures, C.POINTER(A.pt_texture))
+        d.tri_uv = self.tri_uv.ctypes.data if self.tri_uv is not None and len(self.tri_uv) else None
         return d
 
     def table_dims(self, integ_kind):
@@ -421,6 +425,7 @@ def flatten_scene(scene):
     tm = np.empty(len(prims), np.int32)
     tf = np.empty(len(prims), np.int32)
     mats, lobes = [], []
+    uv = None
     for i, pr in enumerate(prims):
         sh = pr.shape
         if type(sh).__name__ != 'Triangle':
@@ -428,8 +433,17 @@ def flatten_scene(scene):
         m = sh.mesh
         # shading geometry is the geometric one unless the mesh has BOTH N and S (triangle.py:325):
         # LoopSubdiv meshes carry N only and shade like plain meshes
-        if m.uvs is not None or (m.n is not None and m.s is not None) or m.alphaTexture is not None:
-            raise NotImplementedError('meshes with uv / N+S shading frames / alpha are outside the supported hot path')
+        if (m.n is not None and m.s is not None) or m.alphaTexture is not None:
+            raise NotImplementedError('meshes with N+S shading frames / alpha are outside the supported hot path')
+        if m.uvs is not None:
+            # Triangle.get_uvs reads mesh.uvs by the triangle's position in the INDEX list, not through
+            # vertexIndex (triangle.py:129-131): corner k of the triangle at slot v has uvs[2(v+k)], uvs[2(v+k)+1]
+            if 2 * (sh.v + 2) + 1 >= len(m.uvs):
+                raise ValueError('mesh.uvs is too short for triangle slot %d: the reference raises IndexError at '
+                                 'the first hit of this triangle (triangle.py:129-131)' % sh.v)
+            if uv is None:
+                uv = np.tile(np.array([0., 0., 1., 0., 1., 1.]), (len(prims), 1))
+            uv[i] = [m.uvs[2 * (sh.v + k) + c] for k in range(3) for c in range(2)]
         if getattr(pr, 'areaLight', None) is not None:
             raise NotImplementedError('emissive primitives are outside the supported hot path')
         for k in range(3):
@@ -442,7 +456,7 @@ def flatten_scene(scene):
             lobes.append(lobes_from_params(kind, **params))
             mid = len(mats) - 1
         tm[i] = mid
-    return FlatScene(nb, nm, tv, tm, tf, lobes, [light_record(l) for l in scene.lights])
+    return FlatScene(nb, nm, tv, tm, tf, lobes, [light_record(l) for l in scene.lights], tri_uv=uv)
 
 
 _MAT_KINDS = {0: 'matte', 1: 'uber', 2: 'plastic', 3: 'mirror', 4: 'glass', 5: 'metal'}
@@ -463,7 +477,8 @@ def flat_scene_from_npz(d):
     for i in range(int(d['n_lights'])):
         pre = 'light%d_' % i
         lights.append({k[len(pre):]: (d[k].item() if d[k].ndim == 0 else d[k]) for k in d.keys() if k.startswith(pre)})
-    return FlatScene(d['node_bounds'], d['node_meta'], d['tri_verts'], d['tri_mat'], d['tri_flip'], lobes, lights)
+    return FlatScene(d['node_bounds'], d['node_meta'], d['tri_verts'], d['tri_mat'], d['tri_flip'], lobes, lights,
+                     tri_uv=d['tri_uv'] if 'tri_uv' in d else None)
 
 
 # --------------------------------------------------------------------------------------

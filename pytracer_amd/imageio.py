@@ -64,6 +64,9 @@ def render_key(flat, cam, film, smp, integ, tile, sampler_mode='device'):
         h.update(np.ascontiguousarray(a).tobytes())
     h.update(bytes(flat._materials))          # packed pt_material / pt_light records (zero-filled padding)
     h.update(bytes(flat._lights))
+    h.update(bytes(flat._textures))
+    if flat.tri_uv is not None:
+        h.update(flat.tri_uv.tobytes())
     for d in (cam, film, smp, integ, tile):
         h.update(bytes(d))
     h.update(sampler_mode.encode())

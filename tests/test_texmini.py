@@ -16,7 +16,9 @@ from test_c4mini import load, rays_from_log, rel_err, descs
 RTOL = 1e-9
 CASES = [('texmini_direct_24x24x1.npz', A.PT_INTEG_DIRECT), ('texmini_path_24x24x4.npz', A.PT_INTEG_PATH),
          ('tex2mini_direct_24x24x1.npz', A.PT_INTEG_DIRECT), ('tex2mini_path_24x24x4.npz', A.PT_INTEG_PATH),
-         ('tex2mini_whitted_24x24x1.npz', A.PT_INTEG_WHITTED)]
+         ('tex2mini_whitted_24x24x1.npz', A.PT_INTEG_WHITTED),
+         # meshes with uv coordinates (26 of them degenerate: coordinate_system fallback, triangle.py:219-221)
+         ('uvmini_direct_24x24x1.npz', A.PT_INTEG_DIRECT), ('uvmini_path_24x24x4.npz', A.PT_INTEG_PATH)]
 
 
 def test_scene_has_textured_lobes(golden_dir):
@@ -99,7 +101,7 @@ def test_oracle_matches_reference(golden_dir, name, kind):
     assert rel_err(L, d['L']) < 1e-8
     np.testing.assert_allclose(acc[..., 0:3], d['film_Lxyz'], rtol=1e-8, atol=1e-10)
     kinds = d['log_rays'][:, 1].astype(int)
-    if kind == A.PT_INTEG_PATH or name.startswith('texmini'):
+    if kind == A.PT_INTEG_PATH or not name.startswith('tex2mini'):
         assert st.rays_closest == int((kinds == 0).sum()) and st.rays_any == int((kinds == 1).sum())
     else:
         # Direct / Whitted on glass: the reference also traces specular_transmit subtrees whose radiance it then
@@ -158,3 +160,34 @@ def test_gpu_matches_reference_and_oracle(ctx, golden_dir, name, kind):
     o2, _ = O.OracleScene(flat).render(cam, film, smp2, pa.integrator_desc(kind, 5, False), tile2, want_L=False)
     a2 = acc2.cpu().numpy()
     assert np.abs(a2 - o2).max() <= 1e-9 * np.abs(o2).max()
+
+
+def test_mesh_uvs_change_the_frames(golden_dir):
+    """The uv fixture without its tri_uv array renders differently: the uvs reach dpdu/dpdv (BSDF frame) and the
+    texture lookups.  And flatten reads mesh.uvs by index-list slot like Triangle.get_uvs (triangle.py:129-131)."""
+    d = load(golden_dir, 'uvmini_direct_24x24x1.npz')
+    assert d['tri_uv'].shape == (len(d['tri_verts']), 6)
+    flat = pa.flat_scene_from_npz(d)
+    assert flat.desc().tri_uv
+    cam, film, smp, tile = descs(d)
+    integ = pa.integrator_desc(A.PT_INTEG_DIRECT, 5, True)
+    _, L = O.OracleScene(flat).render(cam, film, smp, integ, tile, table=d['samples'])
+    plain = {k: v for k, v in d.items() if k != 'tri_uv'}
+    _, L2 = O.OracleScene(pa.flat_scene_from_npz(plain)).render(cam, film, smp, integ, tile, table=d['samples'])
+    assert rel_err(L, d['L']) < 1e-8 and rel_err(L2, d['L']) > 1e-3
+    # stand-in mesh: two triangles, uvs per index slot
+    mesh = _make('TriangleMesh', dict(uvs=[0., 0., 1., 0., 1., 1., .2, .3, .4, .5, .6, .9], n=None, s=None, alphaTexture=None,
+                                      p=[np.zeros(3), np.array([1., 0, 0]), np.array([0., 1, 0]), np.array([0., 0, 1])],
+                                      vertexIndex=[0, 1, 2, 1, 2, 3]))
+    mat = _make('MatteMaterial', dict(Kd=_make('ConstantTexture', dict(value=np.full(3, .5))),
+                                      sigma=_make('ConstantTexture', dict(value=0.)), bump_map=None))
+    prims = [_make('GeometricPrimitive', dict(shape=_make('Triangle', dict(mesh=mesh, v=3 * k, ro=False,
+                                                                             transform_swaps_handedness=False)),
+                                              material=mat, areaLight=None)) for k in range(2)]
+    nodes = [_make('Node', dict(bounds=_make('BBox', dict(pMin=np.zeros(3), pMax=np.ones(3))), offset=0, n_prim=2, axis=0))]
+    scene = _make('Scene', dict(aggregate=_make('BVH', dict(nodes=nodes, primitives=prims)), lights=[]))
+    flat = F.flatten_scene(scene)
+    np.testing.assert_array_equal(flat.tri_uv, [[0., 0., 1., 0., 1., 1.], [.2, .3, .4, .5, .6, .9]])
+    mesh.uvs = mesh.uvs[:8]
+    with pytest.raises(ValueError):
+        F.flatten_scene(scene)

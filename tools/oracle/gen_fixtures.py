@@ -98,11 +98,15 @@ def dump_scene(scene, camera=None):
     tri_src = np.empty((P, 2), np.int32)   # (mesh ordinal, triangle number in mesh)
     mats = []
     meshes = []
+    uvs, has_uv = [], False
     for i, pr in enumerate(agg.primitives):
         sh = pr.shape
         m = sh.mesh
         # shading geometry == geometric unless the mesh has BOTH N and S (triangle.py:325)
-        assert m.uvs is None and (m.n is None or m.s is None) and m.alphaTexture is None
+        assert (m.n is None or m.s is None) and m.alphaTexture is None
+        if m.uvs is not None:
+            has_uv = True
+        uvs.append(np.array(sh.get_uvs(), np.float64).ravel())      # the reference's own per-triangle (u,v) corners
         for k in range(3):
             verts[i, 3 * k:3 * k + 3] = m.p[m.vertexIndex[sh.v + k]]
         flip[i] = int(bool(sh.ro) ^ bool(sh.transform_swaps_handedness))
@@ -115,6 +119,8 @@ def dump_scene(scene, camera=None):
         assert pr.areaLight is None
     d = dict(node_bounds=bounds, node_meta=meta, tri_verts=verts, tri_flip=flip, tri_mat=matid,
              tri_src=tri_src)
+    if has_uv:
+        d['tri_uv'] = np.array(uvs)
     # raw material parameters (ConstantTexture values)
     mrec = []
     for mt in mats:
@@ -548,10 +554,25 @@ class C4Mini(object):
                                  ConstantTexture(.2), c3([1., 1., 1.]), ConstantTexture(1.33)),
                     MatteMaterial(c3([.5, .5, .5]), ConstantTexture(0.))]
             nmesh = 3
+        if variant == 'uv':
+            # meshes WITH uv coordinates (dpdu/dpdv, hence the BSDF frame, and the texture lookups follow them);
+            # every 7th triangle has a degenerate parametrisation (det == 0: coordinate_system fallback)
+            from pytracer.texture.texture import Chekcerboard2DTexture, UVTexture
+            from pytracer.texture.texturemap import UVMapping2D
+            c3 = lambda v: ConstantTexture(Spectrum(v))
+            mats = [MatteMaterial(Chekcerboard2DTexture(UVMapping2D(5., 5., 0., 0.), c3([.8, .3, .2]), c3([.2, .3, .8])),
+                                  ConstantTexture(25.)),
+                    PlasticMaterial(UVTexture(UVMapping2D(2., 2., .25, .25)), c3([.3, .3, .3]), ConstantTexture(0.05)),
+                    MatteMaterial(c3([.5, .5, .5]), ConstantTexture(20.))]
         for k in range(nmesh):
             P = tri[k::nmesh].reshape(-1, 3)
-            mesh = create_triangle_mesh(ident, ident.inverse(), False,
-                                        {'indices': list(range(len(P))), 'P': list(P.ravel())})
+            mp = {'indices': list(range(len(P))), 'P': list(P.ravel())}
+            if variant == 'uv':
+                uvr = np.random.default_rng(99 + k).uniform(0., 1., (len(P) // 3, 3, 2))
+                uvr[::7, 1] = uvr[::7, 0]
+                uvr[::7, 2] = uvr[::7, 0]
+                mp['uv'] = list(uvr.ravel())
+            mesh = create_triangle_mesh(ident, ident.inverse(), False, mp)
             prims.append(GeometricPrimitive(mesh, mats[k]))
             self.in_tris.append(P.reshape(-1, 9))
         wall = {'indices': [0, 1, 2, 2, 0, 3], 'P': [-30, -30, 9, 30, -30, 9, 30, 30, 9, -30, 30, 9]}
@@ -565,7 +586,7 @@ class C4Mini(object):
         lights = [SpotLight(spot_l2w, Spectrum(200.), 30., 25.),
                   PointLight(Transform.translate(geo.Vector(8., -6., -12.)), Spectrum(150.)),
                   DiffuseAreaLight(st, Spectrum(10.), 2, sph)]
-        if variant in ('spec', 'xtra', 'tex', 'tex2'):
+        if variant in ('spec', 'xtra', 'tex', 'tex2', 'uv'):
             lights = lights[1:]
         self.scene = Scene(BVH(prims), lights, None)
 
@@ -907,6 +928,24 @@ def gen_tex2():
 
 
 ALL['tex2'] = gen_tex2
+
+
+def gen_uv():
+    """Meshes with uv coordinates (shape/triangle.py:125-131,209-231) under Direct and Path."""
+    model = C4Mini('uv')
+    cam = model.configure_camera(x_res=24, y_res=24, file_name='/tmp/_fixture.png')
+    sc = dump_scene(model.scene, cam)
+    for name, integ, xs in (('direct', DirectLightingIntegrator(), 1), ('path', PathIntegrator(max_depth=5), 2)):
+        t = time.time()
+        d = instrumented_render(model, 24, 24, xs, xs, integ, seed=51)
+        d.update(sc)
+        np.savez_compressed(os.path.join(OUT, 'uvmini_%s_24x24x%d.npz' % (name, xs * xs)), **d)
+        print('uvmini %s: %.1fs, rays logged %d, sumL %.6f, zero-L %d of %d, degenerate uv triangles %d' % (
+            name, time.time() - t, len(d['log_rays']), d['L'].sum(), int((d['L'].sum(1) == 0).sum()), len(d['L']),
+            int((np.abs(sc['tri_uv'][:, 0:2] - sc['tri_uv'][:, 2:4]).sum(1) == 0).sum())), flush=True)
+
+
+ALL['uv'] = gen_uv
 
 
 if __name__ == '__main__':
