@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 8
+#define PT_ABI_VERSION 9
 
 typedef enum {
     PT_OK = 0,
@@ -47,9 +47,17 @@ typedef enum {
     PT_LOBE_SPEC_REFLECT = 3,     /* bdf.py:229-256; R; FresnelDielectric(a,b); c!=0 →
                                      FresnelFullReflect (fresnel.py:75-83)                  */
     PT_LOBE_SPEC_TRANSMIT = 4,    /* bdf.py:259-307; R=T, a=ei, b=et                        */
-    PT_LOBE_MICROFACET_BLINN_COND = 5 /* the same Microfacet/Blinn with FresnelConductor(eta[3],
+    PT_LOBE_MICROFACET_BLINN_COND = 5,/* the same Microfacet/Blinn with FresnelConductor(eta[3],
                                      k[3]) (fresnel.py:30-41, reflection/utility.py:60-73):
                                      MetalMaterial, material.py:242-258; c = exponent        */
+    PT_LOBE_MEASURED_IRISO = 6    /* IrIsotropicBRDF of MeasuredMaterial (reflection/bdf/measured.py:39-66,
+                                     material.py:403-524): REFLECTION|GLOSSY, f = Gaussian-weighted mean of
+                                     the measured samples inside a ball around brdf_remap(wo, wi)
+                                     (reflection/utility.py:76-90) whose radius grows from .01 by 1.414
+                                     until it holds more than 2 samples or exceeds 1.5; sampled and
+                                     weighted like every base BDF (bdf.py:97-126).  a = first sample,
+                                     b = number of samples (integers) in pt_scene_desc.brdf_p / brdf_v;
+                                     R, c, eta, k unused                                     */
 } pt_lobe_type;
 
 #define PT_MAX_LOBES 5
@@ -135,6 +143,11 @@ typedef struct {
     const double *tri_uv;        /* host [n_tris][6] or NULL: (u,v) of the triangle's three corners as
                                     Triangle.get_uvs returns them (shape/triangle.py:125-131; NULL = the
                                     default (0,0),(1,0),(1,1) for every triangle) */
+    int64_t n_brdf_samples;      /* measured BRDF samples of all MeasuredMaterials, table after table */
+    const double *brdf_p;        /* host [n_brdf_samples][3]: IrIsotropicBRDFSample.p = brdf_remap(wo, wi) of
+                                    the measurement (material.py:471-476) = the cKDTree's data */
+    const double *brdf_v;        /* host [n_brdf_samples][3]: IrIsotropicBRDFSample.v, the RGB the reference
+                                    made of the measured spectrum (Spectrum.from_sampled, material.py:473) */
 } pt_scene_desc;
 
 /* ---- camera (camera/projective.py:42-59; OrthoCamera :65-127; PerspectiveCamera

@@ -97,6 +97,8 @@ typedef struct {
     int32_t n_textures;
     pt_texture *textures;
     double *tri_uv;        /* [n_tris][6] or NULL */
+    int64_t n_brdf;
+    double *brdf_p, *brdf_v;   /* [n_brdf][3] measured BRDF samples (PT_LOBE_MEASURED_IRISO) */
 } oscene;
 
 static void *dupmem(const void *p, size_t n) {
@@ -122,12 +124,28 @@ int pto_scene_create(const pt_scene_desc *d, void **out) {
     s->n_textures = d->n_textures;
     s->textures = (pt_texture *)dupmem(d->textures, sizeof(pt_texture) * d->n_textures);
     s->tri_uv = d->tri_uv ? (double *)dupmem(d->tri_uv, sizeof(double) * 6 * d->n_tris) : NULL;
+    s->n_brdf = d->n_brdf_samples;
+    s->brdf_p = (double *)dupmem(d->brdf_p, sizeof(double) * 3 * (size_t)(d->n_brdf_samples > 0 ? d->n_brdf_samples : 0));
+    s->brdf_v = (double *)dupmem(d->brdf_v, sizeof(double) * 3 * (size_t)(d->n_brdf_samples > 0 ? d->n_brdf_samples : 0));
     for (int i = 0; i < d->n_materials; i++)
-        for (int k = 0; k < s->materials[i].n_lobes; k++)
-            if (s->materials[i].lobes[k].tex < 0 || (s->materials[i].lobes[k].tex & 0xFFFF) > d->n_textures) {
+        for (int k = 0; k < s->materials[i].n_lobes; k++) {
+            pt_lobe *l = &s->materials[i].lobes[k];
+            if (l->tex < 0 || (l->tex & 0xFFFF) > d->n_textures) {
                 pto_scene_destroy(s);
                 return PT_ERR_ARG;
             }
+            if (l->type == PT_LOBE_MEASURED_IRISO) {
+                /* the lobe functions see no scene: this private copy of the lobe carries the addresses of
+                 * its table in the fields the ABI leaves unused for this lobe type */
+                if (!(l->a >= 0. && l->b >= 0. && l->a + l->b <= (double)s->n_brdf)) {
+                    pto_scene_destroy(s);
+                    return PT_ERR_ARG;
+                }
+                const double *pp = s->brdf_p + 3 * (size_t)l->a, *pv = s->brdf_v + 3 * (size_t)l->a;
+                memcpy(&l->eta[0], &pp, sizeof(pp));
+                memcpy(&l->eta[1], &pv, sizeof(pv));
+            }
+        }
     *out = s;
     return PT_OK;
 }
@@ -136,7 +154,8 @@ int pto_scene_destroy(void *p) {
     oscene *s = (oscene *)p;
     if (!s) return PT_OK;
     free(s->node_bounds); free(s->node_meta); free(s->tri_verts); free(s->tri_mat);
-    free(s->tri_flip); free(s->materials); free(s->lights); free(s->textures); free(s->tri_uv); free(s);
+    free(s->tri_flip); free(s->materials); free(s->lights); free(s->textures); free(s->tri_uv);
+    free(s->brdf_p); free(s->brdf_v); free(s);
     return PT_OK;
 }
 
@@ -413,7 +432,8 @@ static inline v3 l2w(const overtex *vx, v3 v) {
 static inline unsigned lobe_flags(int type) {
     switch (type) {
     case PT_LOBE_LAMBERT: case PT_LOBE_OREN_NAYAR: return BDF_REFLECTION | BDF_DIFFUSE;
-    case PT_LOBE_MICROFACET_BLINN: case PT_LOBE_MICROFACET_BLINN_COND: return BDF_REFLECTION | BDF_GLOSSY;
+    case PT_LOBE_MICROFACET_BLINN: case PT_LOBE_MICROFACET_BLINN_COND: case PT_LOBE_MEASURED_IRISO:
+        return BDF_REFLECTION | BDF_GLOSSY;     /* measured.py:47 */
     case PT_LOBE_SPEC_REFLECT: return BDF_REFLECTION | BDF_SPECULAR;
     default: return BDF_TRANSMISSION | BDF_SPECULAR;
     }
@@ -468,6 +488,52 @@ static inline double fr_cond(double cos_i, double eta, double k) {
     return .5 * (r_para_sq + r_perp_sq);
 }
 
+/* geometry/utility.py:115-122 */
+static inline double spherical_phi(v3 v) {
+    double p = atan2(v.y, v.x);
+    return p > 0. ? p : p + 2 * PT_PI;
+}
+/* brdf_remap, reflection/utility.py:76-90 (Marschner's isotropic parametrisation) */
+static v3 brdf_remap(v3 wo, v3 wi) {
+    double dphi = spherical_phi(wi) - spherical_phi(wo);
+    if (dphi < 0.) dphi += 2. * PT_PI;
+    if (dphi > 2. * PT_PI) dphi -= 2. * PT_PI;
+    if (dphi > PT_PI) dphi = 2. * PT_PI - dphi;
+    return V(sin_theta(wi) * sin_theta(wo), dphi * PT_INV_PI, wi.z * wo.z);
+}
+/* IrIsotropicBRDF.f, reflection/bdf/measured.py:51-66.  tree.query_ball_point(m, r) (scipy cKDTree, p = 2)
+ * returns the samples with squared distance <= r*r; restated as a scan of the table.  The reference adds the
+ * samples in the tree's traversal order, this scan in table order: the sums of these positive terms agree to
+ * rounding.  No sample at all (an empty table) gives 0/0 = NaN like the reference. */
+static v3 measured_f(const pt_lobe *l, v3 wo, v3 wi) {
+    const double *pp, *pv;
+    memcpy(&pp, &l->eta[0], sizeof(pp));
+    memcpy(&pv, &l->eta[1], sizeof(pv));
+    const int64_t n = (int64_t)l->b;
+    v3 m = brdf_remap(wo, wi);
+    double max_dist = .01;
+    for (;;) {
+        const double r2 = max_dist * max_dist;
+        int64_t cnt = 0;
+        for (int64_t i = 0; i < n; i++)
+            if (vsqlen(vsub(V(pp[3 * i], pp[3 * i + 1], pp[3 * i + 2]), m)) <= r2) cnt++;
+        if (cnt > 2 || max_dist > 1.5) {
+            double sum_wt = 0.;
+            v3 v = V(0, 0, 0);
+            for (int64_t i = 0; i < n; i++) {
+                double d2 = vsqlen(vsub(V(pp[3 * i], pp[3 * i + 1], pp[3 * i + 2]), m));
+                if (d2 <= r2) {
+                    double wt = exp(d2 * -100.);
+                    sum_wt += wt;
+                    v = vadd(v, vmul(V(pv[3 * i], pv[3 * i + 1], pv[3 * i + 2]), wt));
+                }
+            }
+            return vdiv(V(max0(v.x), max0(v.y), max0(v.z)), sum_wt);     /* v.clip() / sum_wt */
+        }
+        max_dist *= 1.414;
+    }
+}
+
 /* lobe.f(wo, wi) in the local frame */
 static v3 lobe_f(const pt_lobe *l, v3 wo, v3 wi) {
     v3 R = V(l->R[0], l->R[1], l->R[2]);
@@ -512,6 +578,8 @@ static v3 lobe_f(const pt_lobe *l, v3 wo, v3 wi) {
         double D = blinn_D(l->c, wh);
         return vdiv(vmul(vmul(vmul(R, D), G), F), (4. * ct_i * ct_o));
     }
+    case PT_LOBE_MEASURED_IRISO:
+        return measured_f(l, wo, wi);
     default:                                     /* specular lobes: bdf.py:241-246,274-279 */
         return V(0, 0, 0);
     }
@@ -520,7 +588,7 @@ static v3 lobe_f(const pt_lobe *l, v3 wo, v3 wi) {
 /* BDF.pdf (bdf.py:97-106), Microfacet.pdf (torrance.py:225-228), specular pdf = 0 */
 static double lobe_pdf(const pt_lobe *l, v3 wo, v3 wi) {
     switch (l->type) {
-    case PT_LOBE_LAMBERT: case PT_LOBE_OREN_NAYAR:
+    case PT_LOBE_LAMBERT: case PT_LOBE_OREN_NAYAR: case PT_LOBE_MEASURED_IRISO:
         if (wo.z * wi.z > 0.) return fabs(wi.z) * PT_INV_PI;
         return 0.;
     case PT_LOBE_MICROFACET_BLINN: case PT_LOBE_MICROFACET_BLINN_COND:
@@ -535,7 +603,7 @@ static double lobe_pdf(const pt_lobe *l, v3 wo, v3 wi) {
 static double lobe_sample_f(const pt_lobe *l, v3 wo, double u1, double u2, v3 *wi_out, v3 *f_out) {
     v3 R = V(l->R[0], l->R[1], l->R[2]);
     switch (l->type) {
-    case PT_LOBE_LAMBERT: case PT_LOBE_OREN_NAYAR: {
+    case PT_LOBE_LAMBERT: case PT_LOBE_OREN_NAYAR: case PT_LOBE_MEASURED_IRISO: {
         /* BDF.sample_f (bdf.py:108-126) with cosine_sample_hemisphere AS WRITTEN
          * (montecarlo/utility.py:171-184 via uniform_sample_sphere :83-95; Q6) */
         double z = 1. - 2. * u1;
@@ -1293,5 +1361,20 @@ int pto_sample_l(void *scene, int32_t light, const double *p, double pEps, doubl
                     ls.shadow.o.x, ls.shadow.o.y, ls.shadow.o.z, ls.shadow.d.x, ls.shadow.d.y, ls.shadow.d.z,
                     ls.shadow.mint, ls.shadow.maxt, 0, 0, 0};
     memcpy(out, o, sizeof(o));
+    return PT_OK;
+}
+
+/* one lobe of a material, in its local frame: out[11] = f(wo,wi)[3], pdf(wo,wi), then sample_f(wo,u1,u2) = pdf, wi[3], f[3] */
+int pto_lobe_eval(void *scene, int32_t mat, int32_t lobe, const double *wo, const double *wi, double u1, double u2,
+                  double *out) {
+    const oscene *s = (const oscene *)scene;
+    if (mat < 0 || mat >= s->n_materials || lobe < 0 || lobe >= s->materials[mat].n_lobes) return PT_ERR_ARG;
+    const pt_lobe *l = &s->materials[mat].lobes[lobe];
+    v3 o = V(wo[0], wo[1], wo[2]), i = V(wi[0], wi[1], wi[2]), swi = V(0, 0, 0), sf = V(0, 0, 0);
+    v3 f = lobe_f(l, o, i);
+    double pdf = lobe_pdf(l, o, i);
+    double spdf = lobe_sample_f(l, o, u1, u2, &swi, &sf);
+    double r[11] = {f.x, f.y, f.z, pdf, spdf, swi.x, swi.y, swi.z, sf.x, sf.y, sf.z};
+    memcpy(out, r, sizeof(r));
     return PT_OK;
 }

@@ -1,13 +1,13 @@
 """ctypes mirror of include/pytracer_hip.h (struct layouts and enums only)."""
 import ctypes as C
 
-PT_ABI_VERSION = 8
+PT_ABI_VERSION = 9
 PT_MAX_LOBES = 5
 
 PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
 
 (PT_LOBE_LAMBERT, PT_LOBE_OREN_NAYAR, PT_LOBE_MICROFACET_BLINN, PT_LOBE_SPEC_REFLECT, PT_LOBE_SPEC_TRANSMIT,
- PT_LOBE_MICROFACET_BLINN_COND) = range(6)
+ PT_LOBE_MICROFACET_BLINN_COND, PT_LOBE_MEASURED_IRISO) = range(7)
 PT_LIGHT_DIFFUSE_SPHERE, PT_LIGHT_SPOT, PT_LIGHT_POINT = range(3)
 PT_LOBE_DROP_IF_BLACK = 0x10000
 PT_TEX_CHECKER2D, PT_TEX_CHECKER3D, PT_TEX_BILERP, PT_TEX_UV = range(4)
@@ -44,7 +44,8 @@ class pt_scene_desc(C.Structure):
                 ('tri_mat', C.c_void_p), ('tri_flip', C.c_void_p),
                 ('materials', C.POINTER(pt_material)), ('lights', C.POINTER(pt_light)),
                 ('n_textures', C.c_int32), ('_pad', C.c_int32), ('textures', C.POINTER(pt_texture)),
-                ('tri_uv', C.c_void_p)]
+                ('tri_uv', C.c_void_p),
+                ('n_brdf_samples', C.c_int64), ('brdf_p', C.c_void_p), ('brdf_v', C.c_void_p)]
 
 
 class pt_camera(C.Structure):

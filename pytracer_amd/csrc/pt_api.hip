@@ -17,7 +17,7 @@ struct pt_ctx {
     // scene (device)
     bool have_scene;
     DScene sc;
-    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv;
+    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf;
     int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
     int meta_stack;          // todo levels of k_trace_meta's LDS stacks (0: the tree's child words do not fit in LDS)
     int use_meta;            // k_trace_meta when the tree fits: PT_TRACE_META=0 never, 1 (default) closest-hit launches
@@ -163,7 +163,7 @@ static void collect_timing(pt_ctx *c, pt_stats *stats) {
 
 static void free_scene(pt_ctx *c) {
     void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top,
-                   &c->d_tex, &c->d_tex_scratch, &c->d_uv};
+                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -254,7 +254,13 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
         const pt_material &m = d->materials[i];
         if (m.n_lobes < 0 || m.n_lobes > PT_MAX_LOBES) return fail(c, PT_ERR_ARG, "material %d: n_lobes", i);
         for (int k = 0; k < m.n_lobes; k++) {
-            if (m.lobes[k].type < 0 || m.lobes[k].type > PT_LOBE_MICROFACET_BLINN_COND) return fail(c, PT_ERR_ARG, "material %d: lobe type", i);
+            if (m.lobes[k].type < 0 || m.lobes[k].type > PT_LOBE_MEASURED_IRISO) return fail(c, PT_ERR_ARG, "material %d: lobe type", i);
+            if (m.lobes[k].type == PT_LOBE_MEASURED_IRISO) {
+                const double a = m.lobes[k].a, b = m.lobes[k].b;
+                if (!(a >= 0. && b >= 0. && a == floor(a) && b == floor(b) && a + b <= (double)d->n_brdf_samples) ||
+                    (b > 0. && (!d->brdf_p || !d->brdf_v)) || b > 1e9)
+                    return fail(c, PT_ERR_ARG, "material %d: measured BRDF sample range", i);
+            }
             if (m.lobes[k].tex < 0 || (m.lobes[k].tex & 0xFFFF) > d->n_textures || (m.lobes[k].tex & ~(0xFFFF | PT_LOBE_DROP_IF_BLACK))) return fail(c, PT_ERR_ARG, "material %d: texture index", i);
             spec |= m.lobes[k].type == PT_LOBE_SPEC_REFLECT;
         }
@@ -341,7 +347,90 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     HIPCHK(c, upload(&c->d_verts, d->tri_verts, 9 * (size_t)d->n_tris));
     HIPCHK(c, upload(&c->d_mat, d->tri_mat, (size_t)d->n_tris));
     HIPCHK(c, upload(&c->d_flip, d->tri_flip, (size_t)d->n_tris));
-    HIPCHK(c, upload(&c->d_mats, d->materials, (size_t)d->n_materials));
+    // measured BRDF tables: one grid per distinct (first sample, count); the device copy of a measured lobe
+    // carries the index of its grid in `a`
+    std::vector<pt_material> mats(d->materials, d->materials + d->n_materials);
+    {
+        std::vector<std::pair<int64_t, int64_t>> tables;
+        for (auto &m : mats)
+            for (int k = 0; k < m.n_lobes; k++)
+                if (m.lobes[k].type == PT_LOBE_MEASURED_IRISO) {
+                    const std::pair<int64_t, int64_t> key((int64_t)m.lobes[k].a, (int64_t)m.lobes[k].b);
+                    size_t t = 0;
+                    while (t < tables.size() && tables[t] != key) t++;
+                    if (t == tables.size()) tables.push_back(key);
+                    m.lobes[k].a = (double)t;
+                }
+        if (!tables.empty()) {
+            // blob: [BrdfGrid x T][p, v doubles of all tables][cell starts of all tables]
+            size_t n_all = 0, cells_all = 0;
+            std::vector<BrdfGrid> grids(tables.size());
+            for (size_t t = 0; t < tables.size(); t++) {
+                const int64_t n = tables[t].second;
+                int g = (int)ceil(cbrt((double)n / 2.));
+                g = std::min(std::max(g, 1), 32);
+                grids[t].n = (int32_t)n;
+                for (int k = 0; k < 3; k++) grids[t].g[k] = g;
+                n_all += (size_t)n;
+                cells_all += (size_t)g * g * g + 1;
+            }
+            const size_t off_pv = grids.size() * sizeof(BrdfGrid), off_cells = off_pv + n_all * 6 * sizeof(double);
+            std::vector<char> blob(off_cells + cells_all * sizeof(int32_t));
+            HIPCHK(c, hipMalloc(&c->d_brdf, blob.size()));
+            double *pv = (double *)(blob.data() + off_pv);
+            int32_t *cells = (int32_t *)(blob.data() + off_cells);
+            size_t pos = 0, cpos = 0;
+            for (size_t t = 0; t < tables.size(); t++) {
+                BrdfGrid &G = grids[t];
+                const int64_t n = G.n;
+                const double *P = d->brdf_p + 3 * tables[t].first, *V = d->brdf_v + 3 * tables[t].first;
+                double bmax[3];
+                for (int k = 0; k < 3; k++) {
+                    G.bmin[k] = n ? P[k] : 0.;
+                    bmax[k] = G.bmin[k];
+                }
+                for (int64_t i = 0; i < n; i++)
+                    for (int k = 0; k < 3; k++) {
+                        G.bmin[k] = std::min(G.bmin[k], P[3 * i + k]);
+                        bmax[k] = std::max(bmax[k], P[3 * i + k]);
+                    }
+                for (int k = 0; k < 3; k++) {
+                    const double ext = bmax[k] - G.bmin[k];
+                    G.inv[k] = (ext > 0. && std::isfinite(ext)) ? G.g[k] / ext : 0.;
+                    if (!std::isfinite(G.inv[k]) || !std::isfinite(G.bmin[k])) { G.inv[k] = 0.; G.bmin[k] = 0.; }
+                }
+                const size_t nc = (size_t)G.g[0] * G.g[1] * G.g[2];
+                auto cell_of = [&](const double *q) {
+                    int ci[3];
+                    for (int k = 0; k < 3; k++) {           // the same expression as grid_cell (pt_device.h)
+                        const double f = floor((q[k] - G.bmin[k]) * G.inv[k]);
+                        ci[k] = f >= (double)(G.g[k] - 1) ? G.g[k] - 1 : (f > 0. ? (int)f : 0);
+                    }
+                    return ((size_t)ci[2] * G.g[1] + ci[1]) * G.g[0] + ci[0];
+                };
+                int32_t *cs = cells + cpos;
+                std::fill(cs, cs + nc + 1, 0);
+                for (int64_t i = 0; i < n; i++) cs[cell_of(P + 3 * i) + 1]++;
+                for (size_t q = 0; q < nc; q++) cs[q + 1] += cs[q];
+                std::vector<int32_t> fill(cs, cs + nc);
+                double *p_out = pv + pos * 6, *v_out = p_out + (size_t)n * 3;
+                for (int64_t i = 0; i < n; i++) {
+                    const int32_t at = fill[cell_of(P + 3 * i)]++;
+                    memcpy(p_out + 3 * (size_t)at, P + 3 * i, 3 * sizeof(double));
+                    memcpy(v_out + 3 * (size_t)at, V + 3 * i, 3 * sizeof(double));
+                }
+                char *base = (char *)c->d_brdf;
+                G.p = (const double *)(base + off_pv + pos * 6 * sizeof(double));
+                G.v = G.p + (size_t)n * 3;
+                G.cells = (const int32_t *)(base + off_cells + cpos * sizeof(int32_t));
+                pos += (size_t)n;
+                cpos += nc + 1;
+            }
+            memcpy(blob.data(), grids.data(), off_pv);
+            HIPCHK(c, hipMemcpy(c->d_brdf, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        }
+    }
+    HIPCHK(c, upload(&c->d_mats, mats.data(), mats.size()));
     HIPCHK(c, upload(&c->d_lights, d->lights, (size_t)d->n_lights));
     if (d->n_textures > 0) {
         HIPCHK(c, upload(&c->d_tex, d->textures, (size_t)d->n_textures));
@@ -369,6 +458,7 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     s.textures = (const pt_texture *)c->d_tex;
     s.tex_scratch = (pt_material *)c->d_tex_scratch;
     s.tri_uv = (const double *)c->d_uv;
+    s.brdf = (const BrdfGrid *)c->d_brdf;
     s.n_nodes = d->n_nodes; s.n_tris = d->n_tris; s.n_mats = d->n_materials; s.n_lights = d->n_lights;
     memcpy(s.le_sum, le, sizeof(le));
     c->stack_need = std::max(depth, 1);

@@ -96,6 +96,16 @@ struct __attribute__((aligned(16))) TopNode {   // 64 B
     int32_t ref0, ref1;  // first (idx+1) and second (offset) child
 };
 
+// One measured BRDF table (PT_LOBE_MEASURED_IRISO): the samples sorted into a uniform grid over their bounding
+// box, x fastest, so the ball queries of IrIsotropicBRDF.f (reflection/bdf/measured.py:51-66; a scipy cKDTree
+// in the reference) scan the cells a ball overlaps.  Built by pt_scene_upload; all pointers are device memory.
+struct BrdfGrid {
+    double bmin[3], inv[3];    // cell of a point = clamp(floor((p - bmin) * inv), 0, g - 1) per axis
+    int32_t g[3], n;
+    const int32_t *cells;      // [g0*g1*g2 + 1] first sample of every cell
+    const double *p, *v;       // [n][3] sample positions (brdf_remap space) and RGB values, in cell order
+};
+
 struct DScene {
     const GNode *nodes;
     const TopNode *top;        // the first n_top nodes in breadth-first order, or nullptr
@@ -110,6 +120,7 @@ struct DScene {
     const pt_texture *textures;   // referenced by pt_lobe.tex (k > 0: textures[k-1])
     pt_material *tex_scratch;     // one pt_material per shading thread: the textured material at its vertex
     const double *tri_uv;         // [n_tris][6] corner (u,v) of meshes with uvs, or nullptr (triangle.py:125-131)
+    const BrdfGrid *brdf;         // tables of the measured lobes (the device copy of such a lobe has a = table index)
     int32_t n_nodes, n_tris, n_mats, n_lights;
     double le_sum[3];          // Σ light.le over lights (DiffuseAreaLight.le = emit, light.py:503-505)
 };
@@ -128,6 +139,7 @@ struct Vertex {
     d3 p, nn, sn, tn;
     double rEps;
     const pt_material *mat;
+    const BrdfGrid *brdf;      // DScene::brdf (read by k_shade<KIND, 2> only)
 };
 
 // EXT: the scene has textures or mesh uvs (k_shade<KIND, true>); without it the default uvs are compile-time constants
@@ -175,6 +187,7 @@ __device__ inline void make_vertex(const DScene &sc, const Ray &r, int prim, dou
     vx.sn = normalize3(dpdu);
     vx.tn = cross3(vx.nn, vx.sn);
     vx.mat = sc.mats + sc.tri_mat[prim];
+    vx.brdf = sc.brdf;
 }
 
 // ---- textures (texture/texture/__init__.py) over constant children, evaluated where Material.get_bsdf
@@ -277,8 +290,9 @@ __device__ __forceinline__ unsigned lobe_flags(int type) {
     // Lambertian/OrenNayar: REFLECTION|DIFFUSE; Microfacet: REFLECTION|GLOSSY;
     // SpecularReflection: REFLECTION|SPECULAR; SpecularTransmission: TRANSMISSION|SPECULAR
     // (the conductor microfacet lobe, type 5, is REFLECTION|GLOSSY like type 2)
-    const unsigned tab = (5u) | (5u << 5) | (9u << 10) | (17u << 15) | (18u << 20) | (9u << 25);
-    return (tab >> (5 * type)) & 31u;
+    // (so is the measured lobe, type 6: measured.py:47)
+    const unsigned long long tab = (5ull) | (5ull << 5) | (9ull << 10) | (17ull << 15) | (18ull << 20) | (9ull << 25) | (9ull << 30);
+    return (unsigned)(tab >> (5 * type)) & 31u;
 }
 // BDF.match_flag, bdf.py:166-170
 __device__ __forceinline__ bool match_flag(int type, unsigned flags) {
@@ -332,8 +346,64 @@ __device__ inline double blinn_pdf(double e, d3 wo, d3 wi) {
     return ((e + 1.) * pow(ct, e)) / (2. * PT_PI * 4. * dwh);
 }
 
-__device__ inline d3 lobe_f(const pt_lobe &l, d3 wo, d3 wi) {
+// geometry/utility.py:115-122
+__device__ __forceinline__ double spherical_phi(d3 v) {
+    double p = atan2(v.y, v.x);
+    return p > 0. ? p : p + 2 * PT_PI;
+}
+// brdf_remap, reflection/utility.py:76-90
+__device__ inline d3 brdf_remap(d3 wo, d3 wi) {
+    double dphi = spherical_phi(wi) - spherical_phi(wo);
+    if (dphi < 0.) dphi += 2. * PT_PI;
+    if (dphi > 2. * PT_PI) dphi -= 2. * PT_PI;
+    if (dphi > PT_PI) dphi = 2. * PT_PI - dphi;
+    return mk3(sin_theta(wi) * sin_theta(wo), dphi * PT_INV_PI, wi.z * wo.z);
+}
+__device__ __forceinline__ int grid_cell(double x, double bmin, double inv, int g) {
+    const double c = floor((x - bmin) * inv);
+    return c >= (double)(g - 1) ? g - 1 : (c > 0. ? (int)c : 0);     // NaN -> 0
+}
+// IrIsotropicBRDF.f, reflection/bdf/measured.py:51-66: the ball around m grows from .01 by 1.414 until it holds
+// more than two samples or its radius exceeds 1.5; the result is the mean of the samples in it, weighted
+// exp(-100 d^2).  query_ball_point (cKDTree, p = 2) = squared distance <= r*r; here the samples come from the
+// grid cells the ball's bounding box overlaps (padded by a rounding margin), summed in cell order.
+__device__ inline d3 measured_f(const BrdfGrid &g, d3 wo, d3 wi) {
+    const d3 m = brdf_remap(wo, wi);
+    double max_dist = .01;
+    for (;;) {
+        const double r2 = max_dist * max_dist, rp = max_dist * (1. + 1e-9) + 1e-12;
+        const int x0 = grid_cell(m.x - rp, g.bmin[0], g.inv[0], g.g[0]), x1 = grid_cell(m.x + rp, g.bmin[0], g.inv[0], g.g[0]);
+        const int y0 = grid_cell(m.y - rp, g.bmin[1], g.inv[1], g.g[1]), y1 = grid_cell(m.y + rp, g.bmin[1], g.inv[1], g.g[1]);
+        const int z0 = grid_cell(m.z - rp, g.bmin[2], g.inv[2], g.g[2]), z1 = grid_cell(m.z + rp, g.bmin[2], g.inv[2], g.g[2]);
+        int cnt = 0;
+        double sum_wt = 0.;
+        d3 v = mk3(0, 0, 0);
+        for (int z = z0; z <= z1; z++)
+            for (int y = y0; y <= y1; y++) {
+                const int row = (z * g.g[1] + y) * g.g[0];
+                const int e = g.cells[row + x1 + 1];
+                for (int i = g.cells[row + x0]; i < e; i++) {
+                    const d3 d = mk3(g.p[3 * i], g.p[3 * i + 1], g.p[3 * i + 2]) - m;
+                    const double d2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                    if (d2 <= r2) {
+                        const double wt = exp(d2 * -100.);
+                        cnt++;
+                        sum_wt += wt;
+                        v = v + mk3(g.v[3 * i], g.v[3 * i + 1], g.v[3 * i + 2]) * wt;
+                    }
+                }
+            }
+        if (cnt > 2 || max_dist > 1.5) return mk3(max0(v.x), max0(v.y), max0(v.z)) / sum_wt;   // v.clip() / sum_wt
+        max_dist *= 1.414;
+    }
+}
+
+// EXT (here and below): the shade kernels that scenes with measured lobes run (k_shade<KIND, 2>, pt_launch_shade);
+// the measured lobe is compiled into those only, so that the other kernels keep their registers
+template <bool EXT>
+__device__ inline d3 lobe_f(const pt_lobe &l, d3 wo, d3 wi, const BrdfGrid *brdf) {
     d3 R = mk3(l.R[0], l.R[1], l.R[2]);
+    if (EXT && l.type == PT_LOBE_MEASURED_IRISO) return measured_f(brdf[(int)l.a], wo, wi);
     switch (l.type) {
     case PT_LOBE_LAMBERT:   // bdf.py:327-332
         return R * PT_INV_PI;
@@ -378,6 +448,7 @@ __device__ inline double lobe_pdf(const pt_lobe &l, d3 wo, d3 wi) {
     switch (l.type) {
     case PT_LOBE_LAMBERT:
     case PT_LOBE_OREN_NAYAR:
+    case PT_LOBE_MEASURED_IRISO:
         return (wo.z * wi.z > 0.) ? fabs(wi.z) * PT_INV_PI : 0.;
     case PT_LOBE_MICROFACET_BLINN:
     case PT_LOBE_MICROFACET_BLINN_COND:
@@ -388,11 +459,14 @@ __device__ inline double lobe_pdf(const pt_lobe &l, d3 wo, d3 wi) {
     }
 }
 
-__device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, double u2, d3 &wi_out, d3 &f_out) {
+template <bool EXT>
+__device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, double u2, d3 &wi_out, d3 &f_out,
+                                       const BrdfGrid *brdf) {
     d3 R = mk3(l.R[0], l.R[1], l.R[2]);
     switch (l.type) {
     case PT_LOBE_LAMBERT:
-    case PT_LOBE_OREN_NAYAR: {
+    case PT_LOBE_OREN_NAYAR:
+    case PT_LOBE_MEASURED_IRISO: {
         // BDF.sample_f (bdf.py:108-126); cosine_sample_hemisphere AS WRITTEN
         // (montecarlo/utility.py:171-184 on top of uniform_sample_sphere :83-95; Q6)
         double z = 1. - 2. * u1;
@@ -403,7 +477,7 @@ __device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, doubl
         wi.z = sqrt(max0(1. - wi.x * wi.x - wi.y * wi.y));
         if (wo.z < 0.) wi.z *= -1.;
         wi_out = wi;
-        f_out = lobe_f(l, wo, wi);
+        f_out = lobe_f<EXT>(l, wo, wi, brdf);
         return lobe_pdf(l, wo, wi);
     }
     case PT_LOBE_MICROFACET_BLINN:
@@ -421,7 +495,7 @@ __device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, doubl
         if (dwh <= 0.) pdf = 0.;
         wi_out = wi;
         if (wi.z * wo.z <= 0.) f_out = mk3(0, 0, 0);
-        else f_out = lobe_f(l, wo, wi);
+        else f_out = lobe_f<EXT>(l, wo, wi, brdf);
         return pdf;
     }
     case PT_LOBE_SPEC_REFLECT: {   // bdf.py:251-256
@@ -450,13 +524,14 @@ __device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, doubl
 }
 
 // BSDF.f, bsdf.py:207-224
+template <bool EXT>
 __device__ inline d3 bsdf_f(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned flags) {
     d3 wi = w2l(vx, wi_w), wo = w2l(vx, wo_w);
     if (dot3(wi_w, vx.nn) * dot3(wo_w, vx.nn) > 0.) flags &= ~BDF_TRANSMISSION;
     else flags &= ~BDF_REFLECTION;
     d3 f = mk3(0, 0, 0);
     for (int i = 0; i < vx.mat->n_lobes; i++)
-        if (match_flag(vx.mat->lobes[i].type, flags)) f = f + lobe_f(vx.mat->lobes[i], wo, wi);
+        if (match_flag(vx.mat->lobes[i].type, flags)) f = f + lobe_f<EXT>(vx.mat->lobes[i], wo, wi, vx.brdf);
     return f;
 }
 
@@ -474,6 +549,7 @@ __device__ inline double bsdf_pdf(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned f
 // BSDF.f and BSDF.pdf for the same pair of directions (estimate_direct evaluates both,
 // integrator/utility.py:221-231).  Same values as bsdf_f / bsdf_pdf; a Blinn microfacet lobe computes
 // its half vector and |cos θh|^e once for both (pow is the most expensive call of the vertex).
+template <bool EXT>
 __device__ inline d3 bsdf_f_pdf(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned flags, double &pdf_out) {
     d3 wi = w2l(vx, wi_w), wo = w2l(vx, wo_w);
     unsigned fflags = flags;
@@ -502,7 +578,7 @@ __device__ inline d3 bsdf_f_pdf(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned fla
             if (dwh > 0.) pdf += ((l.c + 1.) * pw) / (2. * PT_PI * 4. * dwh);
             continue;
         }
-        if (mf) f = f + lobe_f(l, wo, wi);
+        if (mf) f = f + lobe_f<EXT>(l, wo, wi, vx.brdf);
         if (mp) { n_match++; pdf += lobe_pdf(l, wo, wi); }
     }
     pdf_out = n_match > 0 ? pdf / n_match : 0.;
@@ -511,6 +587,7 @@ __device__ inline d3 bsdf_f_pdf(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned fla
 
 // BSDF.sample_f AS IT EXECUTES, bsdf.py:100-154: `bdf.type & SPECULAR` is an object, always
 // truthy, so the pdf sum (:132-135) and the f re-evaluation (:141-152) never run (Q2).
+template <bool EXT>
 __device__ inline double bsdf_sample_f(const Vertex &vx, d3 wo_w, double u0, double u1, double u_com, unsigned flags,
                                        d3 &wi_w, d3 &f) {
     const pt_material *m = vx.mat;
@@ -529,7 +606,7 @@ __device__ inline double bsdf_sample_f(const Vertex &vx, d3 wo_w, double u0, dou
         }
     if (pick < 0) return 0.;
     d3 wo = w2l(vx, wo_w), wi, fl;
-    double pdf = lobe_sample_f(m->lobes[pick], wo, u0, u1, wi, fl);
+    double pdf = lobe_sample_f<EXT>(m->lobes[pick], wo, u0, u1, wi, fl, vx.brdf);
     if (pdf == 0.) return 0.;
     wi_w = l2w(vx, wi);
     if (n_match > 1) pdf /= n_match;

@@ -732,6 +732,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
 
 // estimate_direct AS IT EXECUTES (integrator/utility.py:203-257; only the light-sampling half
 // contributes, Q3).  Returns true if a shadow ray must be traced; c = contribution if unoccluded.
+template <bool EXT>
 __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, const Vertex &vx, d3 wo, double u0,
                                        double u1, Ray &shadow, d3 &c) {
     const unsigned flags = BDF_ALL & ~BDF_SPECULAR;
@@ -740,7 +741,7 @@ __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, con
     else delta_light_sample_l(lt, vx.p, vx.rEps, ls);
     if (!(ls.pdf > 0. && !util_is_black(ls.Li))) return false;
     double bp = 0.;
-    d3 f = (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) ? bsdf_f_pdf(vx, wo, ls.wi, flags, bp) : bsdf_f(vx, wo, ls.wi, flags);
+    d3 f = (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) ? bsdf_f_pdf<EXT>(vx, wo, ls.wi, flags, bp) : bsdf_f<EXT>(vx, wo, ls.wi, flags);
     if (util_is_black(f)) return false;
     double adot = fabs(dot3(ls.wi, vx.nn));
     if (lt.kind != PT_LIGHT_DIFFUSE_SPHERE) {
@@ -756,13 +757,14 @@ __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, con
 
 // One light of WhittedIntegrator.li (integrator/surface/whitted.py:44-53): no MIS, bsdf.f with the
 // default flags, Spectrum.is_black tests.  Returns true if a shadow ray must be traced.
+template <bool EXT>
 __device__ inline bool estimate_whitted(const DScene &sc, const pt_light &lt, const Vertex &vx, d3 wo, double u0,
                                         double u1, Ray &shadow, d3 &c) {
     LightSample ls;
     if (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) sphere_light_sample_l(lt, vx.p, vx.rEps, u0, u1, ls);
     else delta_light_sample_l(lt, vx.p, vx.rEps, ls);
     if (spec_is_black(ls.Li) || ls.pdf == 0.) return false;
-    d3 f = bsdf_f(vx, wo, ls.wi, BDF_ALL);
+    d3 f = bsdf_f<EXT>(vx, wo, ls.wi, BDF_ALL);
     if (spec_is_black(f)) return false;
     c = (((f * ls.Li) * fabs(dot3(ls.wi, vx.nn))) * 1.) / ls.pdf;   // x transmittance (= 1) / pdf
     shadow = ls.shadow;
@@ -792,8 +794,9 @@ __device__ __forceinline__ void push_shadow(const ShadowQueue &sh, int region, b
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2
 #endif
-// TEX: the scene has textured lobes (compile-time, so that scenes without textures run the kernel unchanged)
-template <int KIND, bool TEX>
+// EXT (compile-time, so that plain scenes run the kernel unchanged): 0 = plain; 1 = the scene has textured lobes or
+// mesh uvs; 2 = it has measured BRDF lobes as well or instead
+template <int KIND, int EXT>
 __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
                                                     int level, Queue qin, HitList hl, Queue qout, ShadowQueue sh,
                                                     PathState st) {
@@ -824,8 +827,8 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
         if (hit) {
             ray.o = mk3(qin.rays[i], qin.rays[S + i], qin.rays[2 * S + i]);
             ray.d = mk3(qin.rays[3 * S + i], qin.rays[4 * S + i], qin.rays[5 * S + i]);
-            make_vertex<TEX>(sc, ray, prim, qin.t[i], vx);
-            if (TEX && sc.textures)
+            make_vertex<EXT != 0>(sc, ray, prim, qin.t[i], vx);
+            if (EXT != 0 && sc.textures)
                 apply_textures(sc, vx, prim, qin.b1[i], qin.b2[i], sc.tex_scratch + ((size_t)blockIdx.x * PT_BLOCK + threadIdx.x));
             wo = -ray.d;
             int px, py, si;
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                 Ray sr;
                 d3 c = mk3(0, 0, 0);
                 if (hit) {
-                    need = estimate_whitted(sc, sc.lights[li], vx, wo, hash_uniform(ss.msid, k),
+                    need = estimate_whitted<EXT == 2>(sc, sc.lights[li], vx, wo, hash_uniform(ss.msid, k),
                                             hash_uniform(ss.msid, k + 1), sr, c);
                     c = T * c;
                 }
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                     if (hit) {
                         double u0, u1;
                         direct_light_uv(ss, off, ns, j, perm, u0, u1);
-                        need = estimate_direct(sc, sc.lights[li], vx, wo, u0, u1, sr, c);
+                        need = estimate_direct<EXT == 2>(sc, sc.lights[li], vx, wo, u0, u1, sr, c);
                         c = T * (c / (double)ns);
                     }
                     push_shadow(sh, region, need, sr, c, slot);
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
             // specular_reflect, integrator/utility.py:120-155 (shared by Direct and Whitted)
             if (hit && (level + 1 < rc.ig.max_depth)) {
                 d3 wi, f;
-                double pdf = bsdf_sample_f(vx, wo, 0., 0., 0., BDF_REFLECTION | BDF_SPECULAR, wi, f);
+                double pdf = bsdf_sample_f<EXT == 2>(vx, wo, 0., 0., 0., BDF_REFLECTION | BDF_SPECULAR, wi, f);
                 double adot = fabs(dot3(wi, vx.nn));
                 if (pdf > 0. && !util_is_black(f) && adot != 0.) {
                     T = T * ((f * adot) / pdf);
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                 }
                 int ln = (int)floor(ulnum * sc.n_lights);
                 if (ln > sc.n_lights - 1) ln = sc.n_lights - 1;
-                need = estimate_direct(sc, sc.lights[ln], vx, wo, u0, u1, sr, c);
+                need = estimate_direct<EXT == 2>(sc, sc.lights[ln], vx, wo, u0, u1, sr, c);
                 c = T * (c * (double)sc.n_lights);
             }
             push_shadow(sh, region, need, sr, c, slot);
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                     uc = hash_uniform(ss.msid, kk + 2);
                 }
                 d3 wi, f;
-                double pdf = bsdf_sample_f(vx, wo, u0, u1, uc, BDF_ALL, wi, f);
+                double pdf = bsdf_sample_f<EXT == 2>(vx, wo, u0, u1, uc, BDF_ALL, wi, f);
                 if (!(spec_is_black(f) || pdf == 0.)) {
                     T = T * ((f * fabs(dot3(wi, vx.nn))) / pdf);
                     cont = true;
@@ -998,10 +1001,12 @@ hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene 
                            const PathState &st) {
     grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
 #define PT_SHADE(K, T) hipLaunchKernelGGL((k_shade<K, T>), dim3(grid), dim3(PT_BLOCK), 0, stream, sc, rc, base, level, qin, hl, qout, sh, st)
-    const bool tex = sc.textures != nullptr || sc.tri_uv != nullptr;
-    if (kind == PT_INTEG_DIRECT) { if (tex) PT_SHADE(PT_INTEG_DIRECT, true); else PT_SHADE(PT_INTEG_DIRECT, false); }
-    else if (kind == PT_INTEG_WHITTED) { if (tex) PT_SHADE(PT_INTEG_WHITTED, true); else PT_SHADE(PT_INTEG_WHITTED, false); }
-    else { if (tex) PT_SHADE(PT_INTEG_PATH, true); else PT_SHADE(PT_INTEG_PATH, false); }
+    const int ext = sc.brdf != nullptr ? 2 : ((sc.textures != nullptr || sc.tri_uv != nullptr) ? 1 : 0);
+#define PT_SHADE_EXT(K) do { if (ext == 2) PT_SHADE(K, 2); else if (ext == 1) PT_SHADE(K, 1); else PT_SHADE(K, 0); } while (0)
+    if (kind == PT_INTEG_DIRECT) PT_SHADE_EXT(PT_INTEG_DIRECT);
+    else if (kind == PT_INTEG_WHITTED) PT_SHADE_EXT(PT_INTEG_WHITTED);
+    else PT_SHADE_EXT(PT_INTEG_PATH);
+#undef PT_SHADE_EXT
 #undef PT_SHADE
     return hipGetLastError();
 }

@@ -62,8 +62,9 @@ def _colour(v, scale=None, drop=False):
 def lobes_from_params(kind, **p):
     """Ordered lobe list [(type, R[3], a, b, c)] for one material record.
 
-    kind: 'matte' | 'uber' | 'plastic' | 'mirror' | 'glass' | 'metal'
-    (a conductor lobe carries two more entries: eta[3], k[3]; a textured lobe ends with {'tex': record})
+    kind: 'matte' | 'uber' | 'plastic' | 'mirror' | 'glass' | 'metal' | 'measured'
+    (a conductor lobe carries two more entries: eta[3], k[3]; a textured lobe ends with {'tex': record}, a
+    measured lobe with {'brdf': (p[n,3], v[n,3])})
     """
     out = []
     textured_ok = {'matte': ('Kd',), 'plastic': ('Kd', 'Ks'), 'uber': ('Kd', 'Ks', 'Kr', 'Kt'), 'mirror': ('Kr',),
@@ -120,6 +121,12 @@ def lobes_from_params(kind, **p):
     elif kind == 'metal':                       # material.py:242-258: Microfacet(Spectrum(1.), FresnelConductor, Blinn)
         out.append((A.PT_LOBE_MICROFACET_BLINN_COND, np.ones(3), 0., 0., _blinn_exponent(float(p['roughness'])),
                     _spec(p['eta']), _spec(p['k'])))
+    elif kind == 'measured':                    # material.py:504-524: one IrIsotropicBRDF over the sample table
+        bp = np.ascontiguousarray(p['brdf_p'], np.float64).reshape(-1, 3)
+        bv = np.ascontiguousarray(p['brdf_v'], np.float64).reshape(-1, 3)
+        if len(bp) != len(bv):
+            raise ValueError('measured BRDF: %d sample positions but %d values' % (len(bp), len(bv)))
+        out.append((A.PT_LOBE_MEASURED_IRISO, np.ones(3), 0., 0., 0., {'brdf': (bp, bv)}))
     else:
         raise NotImplementedError('material kind %r is outside the supported hot path' % (kind,))
     if len(out) > A.PT_MAX_LOBES:
@@ -220,11 +227,25 @@ def material_params(mat):
         return 'glass', dict(Kr=_tex(mat.Kr, True), Kt=_tex(mat.Kt, True), index=_tex(mat.index))
     if nm == 'MetalMaterial':
         return 'metal', dict(eta=_tex(mat.eta), k=_tex(mat.k), roughness=_tex(mat.roughness))
+    if nm == 'MeasuredMaterial':                # material.py:403-524
+        if getattr(mat, 'regular_data', None) is not None:
+            raise NotImplementedError('regular half-angle (MERL) data: the reference cannot load it (material.py:495)')
+        smp = getattr(mat, 'theta_phi_samples', None)
+        if getattr(mat, 'theta_phi_tree', None) is None:
+            raise ValueError('MeasuredMaterial without data: its BSDF has no lobe')
+        if smp is None:
+            # second MeasuredMaterial of one file: __init__ stores the cached samples under a misspelt name
+            # (material.py:434), so IrIsotropicBRDF.data is None and the first f() raises TypeError
+            raise ValueError('MeasuredMaterial built from the IrIsotropicData cache has no samples '
+                             '(material.py:434); the reference fails at the first hit')
+        return 'measured', dict(brdf_p=np.array([np.asarray(x.p, np.float64) for x in smp]).reshape(-1, 3),
+                                brdf_v=np.array([np.asarray(x.v, np.float64) for x in smp]).reshape(-1, 3))
     raise NotImplementedError('material %s is outside the supported hot path' % nm)
 
 
-def _pack_material(lobes, textures=None):
-    """pt_material of a lobe list; textured lobes register their record in `textures` (a list)."""
+def _pack_material(lobes, textures=None, brdfs=None):
+    """pt_material of a lobe list; textured lobes register their record in `textures` (a list), measured lobes
+    their (p, v) sample table in `brdfs` (a list; the lobe gets first sample and count)."""
     m = A.pt_material()
     m.n_lobes = len(lobes)
     for i, lobe in enumerate(lobes):
@@ -238,7 +259,13 @@ def _pack_material(lobes, textures=None):
         if len(lobe) > 5:
             m.lobes[i].eta[:] = [float(x) for x in lobe[5]]
             m.lobes[i].k[:] = [float(x) for x in lobe[6]]
-        if extras is not None:
+        if extras is not None and 'brdf' in extras:
+            if brdfs is None:
+                raise ValueError('measured lobe without a sample table list')
+            m.lobes[i].a = float(sum(len(t[0]) for t in brdfs))
+            m.lobes[i].b = float(len(extras['brdf'][0]))
+            brdfs.append(extras['brdf'])
+        elif extras is not None:
             if textures is None:
                 raise ValueError('textured lobe without a texture table')
             textures.append(extras['tex'])
@@ -341,8 +368,11 @@ class FlatScene(object):
             raise ValueError('material index out of range')
         self._check_tree()
         self.textures = []                     # records referenced by textured lobes, in lobe order
+        brdfs = []                             # (p, v) tables of measured lobes, in lobe order
         self._materials = (A.pt_material * max(1, len(self.material_lobes)))(
-            *[_pack_material(l, self.textures) for l in self.material_lobes])
+            *[_pack_material(l, self.textures, brdfs) for l in self.material_lobes])
+        self.brdf_p = np.ascontiguousarray(np.concatenate([t[0] for t in brdfs]) if brdfs else np.zeros((0, 3)))
+        self.brdf_v = np.ascontiguousarray(np.concatenate([t[1] for t in brdfs]) if brdfs else np.zeros((0, 3)))
         self._textures = (A.pt_texture * max(1, len(self.textures)))(*[_pack_texture(t) for t in self.textures])
         self._lights = (A.pt_light * max(1, len(self.light_records)))(*[_pack_light(r) for r in self.light_records])
 
@@ -395,6 +425,9 @@ class FlatScene(object):
         d.n_textures = len(self.textures)
         d.textures = C.cast(self._textures, C.POINTER(A.pt_texture))
         d.tri_uv = self.tri_uv.ctypes.data if self.tri_uv is not None and len(self.tri_uv) else None
+        d.n_brdf_samples = len(self.brdf_p)
+        d.brdf_p = self.brdf_p.ctypes.data if len(self.brdf_p) else None
+        d.brdf_v = self.brdf_v.ctypes.data if len(self.brdf_v) else None
         return d
 
     def table_dims(self, integ_kind):
@@ -459,7 +492,7 @@ def flatten_scene(scene):
     return FlatScene(nb, nm, tv, tm, tf, lobes, [light_record(l) for l in scene.lights], tri_uv=uv)
 
 
-_MAT_KINDS = {0: 'matte', 1: 'uber', 2: 'plastic', 3: 'mirror', 4: 'glass', 5: 'metal'}
+_MAT_KINDS = {0: 'matte', 1: 'uber', 2: 'plastic', 3: 'mirror', 4: 'glass', 5: 'metal', 6: 'measured'}
 
 
 def flat_scene_from_npz(d):

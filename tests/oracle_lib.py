@@ -44,6 +44,8 @@ def lib():
         L.pto_hit_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
                                        C.c_void_p]
         L.pto_sample_l.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.pto_lobe_eval.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                    C.c_void_p]
         _lib = L
     return _lib
 
@@ -94,6 +96,15 @@ class OracleScene(object):
         out = np.empty(15)
         r = np.ascontiguousarray(ray8, np.float64)
         lib().pto_hit_geometry(self._h, r.ctypes.data, int(prim), float(t), float(b1), float(b2), out.ctypes.data)
+        return out
+
+    def lobe_eval(self, mat, lobe, wo, wi, u1, u2):
+        """f(wo,wi)[3], pdf(wo,wi), sample_f(wo,u1,u2) = pdf, wi[3], f[3] of one lobe in its local frame."""
+        out = np.empty(11)
+        a, b = np.ascontiguousarray(wo, np.float64), np.ascontiguousarray(wi, np.float64)
+        rc = lib().pto_lobe_eval(self._h, int(mat), int(lobe), a.ctypes.data, b.ctypes.data, float(u1), float(u2),
+                                 out.ctypes.data)
+        assert rc == 0, rc
         return out
 
     def sample_l(self, light, p, pEps, u1, u2):

@@ -142,6 +142,9 @@ def dump_scene(scene, camera=None):
         elif nm == 'PlasticMaterial':
             mrec.append(dict(kind=2, Kd=spec_param(mt.Kd), Ks=spec_param(mt.Ks),
                              roughness=float(mt.roughness(None))))
+        elif nm == 'MeasuredMaterial':
+            mrec.append(dict(kind=6, brdf_p=np.array([np.array(x.p) for x in mt.theta_phi_samples]),
+                             brdf_v=np.array([np.array(x.v) for x in mt.theta_phi_samples])))
         else:
             raise NotImplementedError(nm)
     d['n_materials'] = np.int32(len(mrec))
@@ -472,6 +475,26 @@ def gen_bvh():
         print('bvh %s: %.1fs nodes %d hits %d' % (name, time.time() - t, len(bvh.nodes), int(res[:, 0].sum())))
 
 
+def write_synthetic_brdf(path, n_samples, seed, n_wl=30):
+    """A synthetic irregularly sampled isotropic BRDF in the text format MeasuredMaterial reads
+    (material/material.py:443-479): '#' comments, the number of wavelengths, the wavelengths, then per sample
+    theta_i phi_i theta_o phi_o and one value per wavelength.  The reference ships no such file."""
+    rng = np.random.default_rng(seed)
+    wls = np.linspace(400., 700., n_wl)
+    with open(path, 'w') as f:
+        f.write('# synthetic irregular isotropic BRDF, %d samples, seed %d\n%d\n' % (n_samples, seed, n_wl))
+        f.write(' '.join('%.17g' % w for w in wls) + '\n')
+        for _ in range(n_samples):
+            thi, tho = np.arccos(rng.uniform(0., 1., 2))
+            phi, pho = rng.uniform(0., 2. * np.pi, 2)
+            base = rng.uniform(.002, .04)
+            tint = 1. + .6 * np.sin(wls / 50. + rng.uniform(0., 6.))
+            gloss = .03 * max(0., np.cos(thi - tho)) ** 8
+            v = base * tint + gloss
+            f.write('%.17g %.17g %.17g %.17g ' % (thi, phi, tho, pho) + ' '.join('%.17g' % x for x in v) + '\n')
+    return path
+
+
 class C4Mini(object):
     """C4 in miniature: a triangle soup with alternating Matte / Plastic materials in
     front of a matte wall, lit by a SpotLight, a PointLight and a sphere DiffuseAreaLight; camera at
@@ -564,6 +587,18 @@ class C4Mini(object):
                                   ConstantTexture(25.)),
                     PlasticMaterial(UVTexture(UVMapping2D(2., 2., .25, .25)), c3([.3, .3, .3]), ConstantTexture(0.05)),
                     MatteMaterial(c3([.5, .5, .5]), ConstantTexture(20.))]
+        if variant == 'meas':
+            # §8(f) rank 3, measured BRDF: two MeasuredMaterials over synthetic irregular isotropic tables
+            # (a dense one and a sparse one whose balls have to grow), Plastic, and a matte wall
+            from pytracer.material import MeasuredMaterial
+            from pytracer.spectral.spectrum import SampledSpectrum
+            SampledSpectrum.init()                  # CIE tables for Spectrum.from_sampled (material.py:473)
+            c3 = lambda v: ConstantTexture(Spectrum(v))
+            mats = [MeasuredMaterial(write_synthetic_brdf('/tmp/_fixture_dense.brdf', 600, 7)),
+                    MeasuredMaterial(write_synthetic_brdf('/tmp/_fixture_sparse.brdf', 40, 8)),
+                    PlasticMaterial(c3([.2, .4, .6]), c3([.3, .3, .3]), ConstantTexture(0.05)),
+                    MatteMaterial(c3([.5, .5, .5]), ConstantTexture(0.))]
+            nmesh = 3
         for k in range(nmesh):
             P = tri[k::nmesh].reshape(-1, 3)
             mp = {'indices': list(range(len(P))), 'P': list(P.ravel())}
@@ -586,7 +621,7 @@ class C4Mini(object):
         lights = [SpotLight(spot_l2w, Spectrum(200.), 30., 25.),
                   PointLight(Transform.translate(geo.Vector(8., -6., -12.)), Spectrum(150.)),
                   DiffuseAreaLight(st, Spectrum(10.), 2, sph)]
-        if variant in ('spec', 'xtra', 'tex', 'tex2', 'uv'):
+        if variant in ('spec', 'xtra', 'tex', 'tex2', 'uv', 'meas'):
             lights = lights[1:]
         self.scene = Scene(BVH(prims), lights, None)
 
@@ -946,6 +981,44 @@ def gen_uv():
 
 
 ALL['uv'] = gen_uv
+
+
+def gen_meas():
+    """§8(f) rank 3 (measured BRDF): C4Mini('meas') under Direct, Path and Whitted, plus a table of direct
+    IrIsotropicBRDF.f / sample_f / pdf evaluations, directions outside the table's range included."""
+    from pytracer.reflection import IrIsotropicBRDF
+    model = C4Mini('meas')
+    cam = model.configure_camera(x_res=24, y_res=24, file_name='/tmp/_fixture.png')
+    sc = dump_scene(model.scene, cam)
+    rng = np.random.default_rng(61)
+    rows = []
+    for mi in (0, 1):
+        mt = [p.material for p in model.scene.aggregate.primitives if type(p.material).__name__ == 'MeasuredMaterial']
+        mt = [m for k, m in enumerate(mt) if m not in mt[:k]][mi]
+        b = IrIsotropicBRDF(mt.theta_phi_tree, mt.theta_phi_samples)
+        for k in range(150):
+            wo = rng.normal(size=3)
+            wi = rng.normal(size=3)
+            if k % 3:                           # mostly unit vectors in one hemisphere; the rest arbitrary (Q1)
+                wo /= np.linalg.norm(wo); wi /= np.linalg.norm(wi)
+                wo[2] = abs(wo[2]); wi[2] = abs(wi[2])
+            u1, u2 = rng.uniform(size=2)
+            f = b.f(geo.Vector(*wo), geo.Vector(*wi))
+            pdf = b.pdf(geo.Vector(*wo), geo.Vector(*wi))
+            spdf, swi, sf = b.sample_f(geo.Vector(*wo), u1, u2)
+            rows.append([mi] + list(wo) + list(wi) + [u1, u2] + list(f) + [pdf, spdf] + list(swi) + list(sf))
+    sc['brdf_eval'] = np.array(rows, np.float64)
+    for name, integ, xs in (('direct', DirectLightingIntegrator(), 1), ('path', PathIntegrator(max_depth=5), 2),
+                            ('whitted', WhittedIntegrator(), 1)):
+        t = time.time()
+        d = instrumented_render(model, 24, 24, xs, xs, integ, seed=61)
+        d.update(sc)
+        np.savez_compressed(os.path.join(OUT, 'measmini_%s_24x24x%d.npz' % (name, xs * xs)), **d)
+        print('measmini %s: %.1fs, rays logged %d, sumL %.6f, zero-L %d of %d' % (
+            name, time.time() - t, len(d['log_rays']), d['L'].sum(), int((d['L'].sum(1) == 0).sum()), len(d['L'])), flush=True)
+
+
+ALL['meas'] = gen_meas
 
 
 if __name__ == '__main__':
