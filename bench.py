@@ -43,13 +43,15 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--res', type=int, default=1024)
-    ap.add_argument('--spp', type=int, default=8, help='strata per axis (spp = spp^2)')
+    ap.add_argument('--spp', type=int, default=8, help='strata per axis (spp = spp^2; c5: spp x spp/2)')
     ap.add_argument('--integrator', choices=['path', 'direct'], default='path')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', choices=['head', 'c2', 'c4'], default='head',
+    ap.add_argument('--workload', choices=['head', 'c2', 'c4', 'c5'], default='head',
                     help='head = BASELINE.json configs[2] (the metric; default).  Secondary, for DESIGN.md only: '
                          'c2 = configs[1] head_loop 512^2 x 16 spp Direct; c4 = configs[3] 10^6-triangle soup '
-                         '1920x1080 Path (use --spp 16 for the full 256 spp)')
+                         '1920x1080 Path (use --spp 16 for the full 256 spp); c5 = configs[4] as far as the reference '
+                         'can run it: head mesh with a measured isotropic BRDF (RGB) + checkerboard backdrop, 1024^2, '
+                         '16x8 = 128 spp Path')
     return ap.parse_args()
 
 
@@ -134,6 +136,7 @@ def main():
     dev = torch.device('cuda', local if world > 1 else 0)
 
     res, xs = args.res, args.spp
+    ys = None
     kind = A.PT_INTEG_PATH if args.integrator == 'path' else A.PT_INTEG_DIRECT
     xres = yres = res
     if args.workload == 'head':
@@ -150,6 +153,14 @@ def main():
         kind = A.PT_INTEG_DIRECT
         cam, film = host.head_mesh_camera_film(res, res)
         wname = 'head_loop (Loop-subdivided head) %dx%d, %d spp, %s, Lanczos(4,4,3) film (BASELINE.json configs[1])'
+    elif args.workload == 'c5':
+        from pytracer_amd import workloads
+        flat = workloads.c5_head_measured(os.path.join(ROOT, 'tests', 'golden', 'head_mesh_scene.npz'))
+        xs = 16 if args.spp == 8 else args.spp
+        ys = max(xs // 2, 1)
+        cam, film = host.head_mesh_camera_film(res, res)
+        wname = ('head_mesh with a measured isotropic BRDF (1000 RGB samples) + checkerboard backdrop %dx%d, %d spp, %s '
+                 'max_depth 5 (BASELINE.json configs[4], RGB: the reference hard-wires Spectrum = RGBSpectrum)')
     else:
         from pytracer_amd import workloads
         flat = workloads.c4_soup()
@@ -161,8 +172,9 @@ def main():
     ctx.upload(flat)
     ctx.set_profiling(True)
     integ = pa.integrator_desc(kind, 5, pretest=False)
-    smp = pa.sampler_desc(0, xres, 0, yres, xs, xs, True, seed=rank)
-    tile = pa.tile_desc(0, xres, 0, yres, 0, xs * xs)
+    ys = xs if ys is None else ys
+    smp = pa.sampler_desc(0, xres, 0, yres, xs, ys, True, seed=rank)
+    tile = pa.tile_desc(0, xres, 0, yres, 0, xs * ys)
     acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device=dev)
 
     def barrier():
@@ -231,7 +243,7 @@ def main():
             'samples_per_s': samples_total / dt,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': wname % (xres, yres, xs * xs, 'PathIntegrator' if kind else 'DirectLightingIntegrator'),
+            'config': {'workload': wname % (xres, yres, xs * ys, 'PathIntegrator' if kind else 'DirectLightingIntegrator'),
                        'triangles': flat.n_tris, 'bvh_nodes': flat.n_nodes,
                        'rays_per_sample': rays_total / max(samples_total, 1),
                        'parallelism': 'replicated scene, per-rank sample streams, RCCL film reduce'

@@ -68,6 +68,62 @@ def c4_camera_film(x_res=1920, y_res=1080):
     return cam, host.image_film(x_res, y_res, 'lanczos', 4., 4., tau=3.)
 
 
+def brdf_remap(wo, wi):
+    """reflection/utility.py:76-90 for arrays of unit directions [n,3] (host side: synthetic tables only)."""
+    def sph_phi(v):
+        p = np.arctan2(v[:, 1], v[:, 0])
+        return np.where(p > 0., p, p + 2. * np.pi)
+    dphi = sph_phi(wi) - sph_phi(wo)
+    dphi = np.where(dphi < 0., dphi + 2. * np.pi, dphi)
+    dphi = np.where(dphi > 2. * np.pi, dphi - 2. * np.pi, dphi)
+    dphi = np.where(dphi > np.pi, 2. * np.pi - dphi, dphi)
+    st = lambda v: np.sqrt(np.maximum(0., 1. - v[:, 2] * v[:, 2]))
+    return np.stack([st(wi) * st(wo), dphi / np.pi, wi[:, 2] * wo[:, 2]], axis=1)
+
+
+def synthetic_brdf_table(n_samples=1000, seed=5):
+    """(p[n,3], v[n,3]) of a synthetic irregularly sampled isotropic BRDF in the form a loaded MeasuredMaterial
+    holds it (material.py:463-479): positions = brdf_remap of uniformly drawn upper-hemisphere direction pairs,
+    values = RGB (a tinted diffuse base plus a lobe around the mirror direction).  The reference ships no .brdf file."""
+    rng = np.random.default_rng(seed)
+
+    def dirs(n):
+        z = rng.uniform(0., 1., n)
+        ph = rng.uniform(0., 2. * np.pi, n)
+        r = np.sqrt(np.maximum(0., 1. - z * z))
+        return np.stack([r * np.cos(ph), r * np.sin(ph), z], axis=1)
+    wo, wi = dirs(n_samples), dirs(n_samples)
+    wh = wo + wi
+    wh /= np.linalg.norm(wh, axis=1, keepdims=True)
+    gloss = .8 * wh[:, 2] ** 40
+    base = np.array([.30, .22, .15]) * rng.uniform(.8, 1.2, (n_samples, 1))
+    return brdf_remap(wo, wi), base / np.pi + gloss[:, None]
+
+
+def c5_head_measured(head_npz, n_samples=1000, seed=5):
+    """configs[4] as far as the reference can run it: the head mesh of examples/head_mesh.py with a
+    MeasuredMaterial (irregular isotropic table, `n_samples` RGB samples) in place of its Uber material and a
+    closed-form checkerboard (UV mapping) as the backdrop's Kd."""
+    from .flatten import flat_scene_from_npz
+    d = dict(np.load(head_npz))
+    head = [i for i in range(int(d['n_materials'])) if int(d['mat%d_kind' % i]) == 1][0]
+    back = [i for i in range(int(d['n_materials'])) if int(d['mat%d_kind' % i]) == 0][0]
+    for k in [k for k in d if k.startswith('mat%d_' % head)]:
+        del d[k]
+    p, v = synthetic_brdf_table(n_samples, seed)
+    d['mat%d_kind' % head] = np.int32(6)
+    d['mat%d_brdf_p' % head], d['mat%d_brdf_v' % head] = p, v
+    del d['mat%d_Kd' % back]
+    m = np.zeros(16)
+    m[0:4] = [8., 8., 0., 0.]
+    tv = np.zeros((4, 3))
+    tv[0], tv[1] = [.4, .4, .4], [.05, .05, .05]
+    d['mat%d_Kd_tex_kind' % back] = np.int32(A.PT_TEX_CHECKER2D)
+    d['mat%d_Kd_tex_mapping' % back] = np.int32(A.PT_MAP_UV)
+    d['mat%d_Kd_tex_m' % back], d['mat%d_Kd_tex_v' % back] = m, tv
+    return flat_scene_from_npz(d)
+
+
 def c2_meshes(c2_npz, loop_npz):
     """World-space meshes [(P, idx, material)] of examples/head_loop.py: the head = 3 levels of Loop
     subdivision of the control mesh (examples/head_model.py data, held by loop_subdiv.npz), translated

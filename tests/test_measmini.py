@@ -156,3 +156,36 @@ def test_gpu_rejects_bad_sample_ranges(ctx, golden_dir):
     with pytest.raises(Exception):
         ctx.upload(flat)
     ctx.upload(pa.flat_scene_from_npz(d))
+
+
+@pytest.mark.gpu
+def test_gpu_c5_workload_matches_oracle(ctx, golden_dir):
+    """bench.py --workload c5 in small: the head mesh with a 1000-sample measured table (8x8x8 grid on the device) and a
+    checkerboard backdrop, production sample streams, 16x8 strata like the full configuration: device == oracle."""
+    import os
+    import torch
+    from pytracer_amd import host, workloads
+    flat = workloads.c5_head_measured(os.path.join(golden_dir, 'head_mesh_scene.npz'))
+    assert len(flat.brdf_p) == 1000 and len(flat.textures) == 1
+    ctx.upload(flat)
+    cam, film = host.head_mesh_camera_film(48, 48)
+    smp = pa.sampler_desc(0, 48, 0, 48, 16, 8, True, 3)
+    tile = pa.tile_desc(8, 40, 8, 40, 0, 128)
+    integ = pa.integrator_desc(A.PT_INTEG_PATH, 5, False)
+    acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
+    sg, so = A.pt_stats(), A.pt_stats()
+    ctx.render(cam, film, smp, integ, tile, acc, stats=sg)
+    torch.cuda.synchronize()
+    oacc, _ = O.OracleScene(flat).render(cam, film, smp, integ, tile, stats=so, want_L=False)
+    a = acc.cpu().numpy()
+    # 1e-6 rather than the 1e-9 of the analytic lobes: brdf_remap takes the azimuth difference of wo and wi, which is
+    # ill-conditioned where a direction is nearly parallel to the normal (x, y of the local vector are rounding
+    # residue of the frame dot products), and the Gaussian weights exp(-100 d^2) amplify it.  Measured on this render:
+    # 3 of 131 072 samples differ by more than 1e-9 relative (largest 6.4e-8, a 9e4-radiance outlier), the rest agree
+    # to 1e-11; the film differs by 3.7e-8 of its maximum.
+    assert np.abs(a - oacc).max() <= 1e-6 * np.abs(oacc).max()
+    # (node visits and triangle tests of bounce rays may differ in the last digits: their directions carry the device
+    # libm's sincos / pow, one ulp from glibc's)
+    x, y = sg.as_dict(), so.as_dict()
+    for k in ('camera_samples', 'rays_closest', 'rays_any', 'guard_nan', 'guard_neg', 'guard_inf'):
+        assert x[k] == y[k], (k, x, y)
