@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "pt_kernels.h"
@@ -18,6 +20,7 @@ struct pt_ctx {
     bool have_scene;
     DScene sc;
     void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf;
+    size_t brdf_bytes;
     int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
     int meta_stack;          // todo levels of k_trace_meta's LDS stacks (0: the tree's child words do not fit in LDS)
     int use_meta;            // k_trace_meta when the tree fits: PT_TRACE_META=0 never, 1 (default) closest-hit launches
@@ -362,7 +365,8 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
                     m.lobes[k].a = (double)t;
                 }
         if (!tables.empty()) {
-            // blob: [BrdfGrid x T][p, v doubles of all tables][cell starts of all tables]
+            // blob: [BrdfGrid x T][p, v doubles of all tables][cell starts of all tables][start rounds of all tables],
+            // addressed by byte offsets from its first byte so that k_shade can run it from an LDS copy
             size_t n_all = 0, cells_all = 0;
             std::vector<BrdfGrid> grids(tables.size());
             for (size_t t = 0; t < tables.size(); t++) {
@@ -375,10 +379,14 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
                 cells_all += (size_t)g * g * g + 1;
             }
             const size_t off_pv = grids.size() * sizeof(BrdfGrid), off_cells = off_pv + n_all * 6 * sizeof(double);
-            std::vector<char> blob(off_cells + cells_all * sizeof(int32_t));
+            const size_t off_k = off_cells + cells_all * sizeof(int32_t);
+            const size_t blob_bytes = (off_k + cells_all * sizeof(int32_t) + 7) & ~(size_t)7;
+            if (blob_bytes > ((size_t)1 << 31) - 8) return fail(c, PT_ERR_CAPACITY, "measured BRDF tables exceed 2 GB");
+            std::vector<char> blob(blob_bytes);
             HIPCHK(c, hipMalloc(&c->d_brdf, blob.size()));
             double *pv = (double *)(blob.data() + off_pv);
             int32_t *cells = (int32_t *)(blob.data() + off_cells);
+            int32_t *kstart = (int32_t *)(blob.data() + off_k);
             size_t pos = 0, cpos = 0;
             for (size_t t = 0; t < tables.size(); t++) {
                 BrdfGrid &G = grids[t];
@@ -396,8 +404,10 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
                     }
                 for (int k = 0; k < 3; k++) {
                     const double ext = bmax[k] - G.bmin[k];
-                    G.inv[k] = (ext > 0. && std::isfinite(ext)) ? G.g[k] / ext : 0.;
-                    if (!std::isfinite(G.inv[k]) || !std::isfinite(G.bmin[k])) { G.inv[k] = 0.; G.bmin[k] = 0.; }
+                    const bool ok = ext > 0. && std::isfinite(ext) && std::isfinite(G.bmin[k]) && std::isfinite(G.g[k] / ext);
+                    G.inv[k] = ok ? G.g[k] / ext : 0.;
+                    G.cw[k] = ok ? ext / G.g[k] : 0.;
+                    if (!std::isfinite(G.bmin[k])) G.bmin[k] = 0.;
                 }
                 const size_t nc = (size_t)G.g[0] * G.g[1] * G.g[2];
                 auto cell_of = [&](const double *q) {
@@ -419,13 +429,64 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
                     memcpy(p_out + 3 * (size_t)at, P + 3 * i, 3 * sizeof(double));
                     memcpy(v_out + 3 * (size_t)at, V + 3 * i, 3 * sizeof(double));
                 }
-                char *base = (char *)c->d_brdf;
-                G.p = (const double *)(base + off_pv + pos * 6 * sizeof(double));
-                G.v = G.p + (size_t)n * 3;
-                G.cells = (const int32_t *)(base + off_cells + cpos * sizeof(int32_t));
+                G.off_p = (int32_t)(off_pv + pos * 6 * sizeof(double));
+                G.off_v = G.off_p + (int32_t)((size_t)n * 3 * sizeof(double));
+                G.off_cells = (int32_t)(off_cells + cpos * sizeof(int32_t));
+                G.off_kstart = (int32_t)(off_k + cpos * sizeof(int32_t));
+                // the radii of measured.py:53,66, by the same multiplications; radius[15] = 1.81 is the first > 1.5
+                G.radius[0] = .01;
+                for (int k = 1; k < 16; k++) G.radius[k] = G.radius[k - 1] * 1.414;
+                // kstart[cell]: a ball around ANY point of the cell (border cells reach to infinity outwards: queries
+                // outside the box are clamped into them) holds 3 samples only if its radius reaches the third
+                // smallest sample-to-box distance.  Samples within W cells are examined; one beyond is at least W
+                // cell widths away.
+                {
+                    const int W = 2;
+                    double cw_min = INFINITY, cw_max = 0.;
+                    for (int k = 0; k < 3; k++)
+                        if (G.cw[k] > 0.) {
+                            cw_min = std::min(cw_min, G.cw[k]);
+                            cw_max = std::max(cw_max, G.cw[k]);
+                        }
+                    int32_t *ks = kstart + cpos;
+                    for (int cz = 0; cz < G.g[2]; cz++)
+                        for (int cy = 0; cy < G.g[1]; cy++)
+                            for (int cx = 0; cx < G.g[0]; cx++) {
+                                const int ci[3] = {cx, cy, cz};
+                                double lo[3], hi[3];
+                                for (int k = 0; k < 3; k++) {
+                                    lo[k] = ci[k] == 0 ? -INFINITY : G.bmin[k] + ci[k] * G.cw[k];
+                                    hi[k] = ci[k] == G.g[k] - 1 ? INFINITY : G.bmin[k] + (ci[k] + 1) * G.cw[k];
+                                }
+                                double best[3] = {INFINITY, INFINITY, INFINITY};     // three smallest squared distances
+                                for (int z = std::max(cz - W, 0); z <= std::min(cz + W, G.g[2] - 1); z++)
+                                    for (int y = std::max(cy - W, 0); y <= std::min(cy + W, G.g[1] - 1); y++) {
+                                        const size_t row = ((size_t)z * G.g[1] + y) * G.g[0];
+                                        for (int32_t i = cs[row + std::max(cx - W, 0)]; i < cs[row + std::min(cx + W, G.g[0] - 1) + 1]; i++) {
+                                            double d2 = 0.;
+                                            for (int k = 0; k < 3; k++) {
+                                                const double q = p_out[3 * (size_t)i + k];
+                                                const double dd = q < lo[k] ? lo[k] - q : (q > hi[k] ? q - hi[k] : 0.);
+                                                d2 += dd * dd;
+                                            }
+                                            if (d2 < best[2]) {
+                                                best[2] = d2;
+                                                if (best[2] < best[1]) std::swap(best[1], best[2]);
+                                                if (best[1] < best[0]) std::swap(best[0], best[1]);
+                                            }
+                                        }
+                                    }
+                                double bound = std::min(sqrt(best[2]), W * cw_min);
+                                bound = bound * (1. - 1e-9) - 1e-9 * cw_max;      // rounding of the cell assignment
+                                int k0 = 0;
+                                while (k0 < 15 && G.radius[k0] < bound) k0++;
+                                ks[((size_t)cz * G.g[1] + cy) * G.g[0] + cx] = k0;
+                            }
+                }
                 pos += (size_t)n;
                 cpos += nc + 1;
             }
+            c->brdf_bytes = blob_bytes;
             memcpy(blob.data(), grids.data(), off_pv);
             HIPCHK(c, hipMemcpy(c->d_brdf, blob.data(), blob.size(), hipMemcpyHostToDevice));
         }
@@ -458,7 +519,8 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     s.textures = (const pt_texture *)c->d_tex;
     s.tex_scratch = (pt_material *)c->d_tex_scratch;
     s.tri_uv = (const double *)c->d_uv;
-    s.brdf = (const BrdfGrid *)c->d_brdf;
+    s.brdf = (const char *)c->d_brdf;
+    s.brdf_lds_bytes = (c->d_brdf && c->brdf_bytes + PT_MEAS_HITS * PT_BLOCK * sizeof(int) <= (size_t)64 * 1024 && !getenv("PT_BRDF_NO_LDS")) ? (int32_t)c->brdf_bytes : 0;
     s.n_nodes = d->n_nodes; s.n_tris = d->n_tris; s.n_mats = d->n_materials; s.n_lights = d->n_lights;
     memcpy(s.le_sum, le, sizeof(le));
     c->stack_need = std::max(depth, 1);

@@ -98,12 +98,17 @@ struct __attribute__((aligned(16))) TopNode {   // 64 B
 
 // One measured BRDF table (PT_LOBE_MEASURED_IRISO): the samples sorted into a uniform grid over their bounding
 // box, x fastest, so the ball queries of IrIsotropicBRDF.f (reflection/bdf/measured.py:51-66; a scipy cKDTree
-// in the reference) scan the cells a ball overlaps.  Built by pt_scene_upload; all pointers are device memory.
+// in the reference) scan the cells a ball overlaps.  Built by pt_scene_upload as ONE position-independent blob
+// ([BrdfGrid x tables][p, v][cell starts][start rounds], offsets in bytes from the blob's first byte), which
+// k_shade<KIND, 2> copies into LDS when it fits (DScene::brdf_lds_bytes).
 struct BrdfGrid {
     double bmin[3], inv[3];    // cell of a point = clamp(floor((p - bmin) * inv), 0, g - 1) per axis
+    double cw[3];              // cell widths (0 on an axis where all samples coincide)
+    double radius[16];         // .01 * 1.414^k as the reference's loop produces them (radius[15] is the first > 1.5)
     int32_t g[3], n;
-    const int32_t *cells;      // [g0*g1*g2 + 1] first sample of every cell
-    const double *p, *v;       // [n][3] sample positions (brdf_remap space) and RGB values, in cell order
+    int32_t off_cells;         // int32 [g0*g1*g2 + 1] first sample of every cell
+    int32_t off_kstart;        // int32 [g0*g1*g2] the first k at which a ball around a point of the cell CAN hold 3 samples
+    int32_t off_p, off_v;      // double [n][3] sample positions (brdf_remap space) and RGB values, in cell order
 };
 
 struct DScene {
@@ -120,7 +125,8 @@ struct DScene {
     const pt_texture *textures;   // referenced by pt_lobe.tex (k > 0: textures[k-1])
     pt_material *tex_scratch;     // one pt_material per shading thread: the textured material at its vertex
     const double *tri_uv;         // [n_tris][6] corner (u,v) of meshes with uvs, or nullptr (triangle.py:125-131)
-    const BrdfGrid *brdf;         // tables of the measured lobes (the device copy of such a lobe has a = table index)
+    const char *brdf;             // blob of the measured lobes' tables (the device copy of such a lobe has a = table index)
+    int32_t brdf_lds_bytes;       // size of that blob if k_shade stages it in LDS (it fits in 64 KB), else 0
     int32_t n_nodes, n_tris, n_mats, n_lights;
     double le_sum[3];          // Σ light.le over lights (DiffuseAreaLight.le = emit, light.py:503-505)
 };
@@ -139,7 +145,9 @@ struct Vertex {
     d3 p, nn, sn, tn;
     double rEps;
     const pt_material *mat;
-    const BrdfGrid *brdf;      // DScene::brdf (read by k_shade<KIND, 2> only)
+    const char *brdf;          // the BrdfGrid blob, in HBM or staged in LDS (read by k_shade<KIND, 2> only)
+    bool brdf_in_lds;
+    int *hits;                 // this thread's hit list in LDS (measured_f; k_shade<KIND, 2> only)
 };
 
 // EXT: the scene has textures or mesh uvs (k_shade<KIND, true>); without it the default uvs are compile-time constants
@@ -188,6 +196,8 @@ __device__ inline void make_vertex(const DScene &sc, const Ray &r, int prim, dou
     vx.tn = cross3(vx.nn, vx.sn);
     vx.mat = sc.mats + sc.tri_mat[prim];
     vx.brdf = sc.brdf;
+    vx.hits = nullptr;
+    vx.brdf_in_lds = false;
 }
 
 // ---- textures (texture/texture/__init__.py) over constant children, evaluated where Material.get_bsdf
@@ -346,6 +356,9 @@ __device__ inline double blinn_pdf(double e, d3 wo, d3 wi) {
     return ((e + 1.) * pow(ct, e)) / (2. * PT_PI * 4. * dwh);
 }
 
+#ifndef PT_MEAS_ABL
+#define PT_MEAS_ABL 0
+#endif
 // geometry/utility.py:115-122
 __device__ __forceinline__ double spherical_phi(d3 v) {
     double p = atan2(v.y, v.x);
@@ -365,45 +378,119 @@ __device__ __forceinline__ int grid_cell(double x, double bmin, double inv, int 
 }
 // IrIsotropicBRDF.f, reflection/bdf/measured.py:51-66: the ball around m grows from .01 by 1.414 until it holds
 // more than two samples or its radius exceeds 1.5; the result is the mean of the samples in it, weighted
-// exp(-100 d^2).  query_ball_point (cKDTree, p = 2) = squared distance <= r*r; here the samples come from the
-// grid cells the ball's bounding box overlaps (padded by a rounding margin), summed in cell order.
-__device__ inline d3 measured_f(const BrdfGrid &g, d3 wo, d3 wi) {
+// exp(-100 d^2).  query_ball_point (cKDTree, p = 2) = squared distance <= r*r.  Here the samples come from the grid:
+// per (y, z) row of cells the ball's chord gives the x range (rows the ball misses are skipped), every sample in it
+// is tested exactly, and the sums run in cell order.  The radii below kstart cannot succeed anywhere in m's cell
+// (a bound computed at upload from the distances of the samples to the cell's box), so the loop starts there.
+__device__ __forceinline__ double interval_dist(double x, double lo, double hi) {
+    return x < lo ? lo - x : (x > hi ? x - hi : 0.);
+}
+// One lane = one query, 64 different balls per wave, so the walk is divergent and VALU-bound (rocprofv3: 445 k VALU
+// against 27 k memory instructions per wave).  The samples found inside the ball are only LISTED during the scan
+// (`hits`: PT_MEAS_HITS ints per thread in LDS, thread-strided) and weighted afterwards, so exp() runs
+// max-over-lanes(samples in the ball) times per wave instead of once per scan step (some lane is inside its ball at
+// nearly every step).  Tried and rejected: one flat loop in which a lane either tests a candidate or steps to its
+// next row (rows hold 2-5 candidates, so the ~100-instruction row set-up ran at every step: shade 363 -> 497 ms).
+#define PT_MEAS_HITS 12
+#define PT_MEAS_STRIDE 256   // = PT_BLOCK (pt_kernels.h checks): entry j of a thread's list is hits[j * PT_MEAS_STRIDE]
+// Pointer types of the blob: explicit LDS pointers (ds_read with 32-bit addresses) when k_shade staged it, else
+// global memory.  Through generic pointers every access is a flat instruction with 64-bit address arithmetic.
+#define PT_AS_LDS __attribute__((address_space(3)))
+template <bool LDS> struct MeasPtr {
+    typedef const double *D;
+    typedef const int32_t *I;
+    typedef const BrdfGrid *G;
+    typedef const char *C;
+};
+template <> struct MeasPtr<true> {
+    typedef PT_AS_LDS const double *D;
+    typedef PT_AS_LDS const int32_t *I;
+    typedef PT_AS_LDS const BrdfGrid *G;
+    typedef PT_AS_LDS const char *C;
+};
+typedef PT_AS_LDS int *lds_int_ptr;
+
+template <bool LDS>
+__device__ __forceinline__ void measured_flush(typename MeasPtr<LDS>::D P, typename MeasPtr<LDS>::D V, d3 m, lds_int_ptr hits, int n,
+                                               double &sum_wt, d3 &v) {
+    for (int j = 0; j < n; j++) {
+        const int i = hits[j * PT_MEAS_STRIDE];
+        const d3 d = mk3(P[3 * i], P[3 * i + 1], P[3 * i + 2]) - m;
+        const double d2 = d.x * d.x + d.y * d.y + d.z * d.z;
+#if PT_MEAS_ABL == 3
+        const double wt = 1. - d2;
+#else
+        const double wt = exp(d2 * -100.);
+#endif
+        sum_wt += wt;
+        v = v + mk3(V[3 * i], V[3 * i + 1], V[3 * i + 2]) * wt;
+    }
+}
+template <bool LDS>
+__device__ inline d3 measured_f_as(const char *base_generic, int table, d3 wo, d3 wi, int *hits_generic) {
+#if PT_MEAS_ABL == 1
+    return mk3(.1, .1, .1);
+#endif
+    typedef MeasPtr<LDS> MP;
+    const typename MP::C base = (typename MP::C)base_generic;
+    const lds_int_ptr hits = (lds_int_ptr)hits_generic;
+    const typename MP::G gp = (typename MP::G)base + table;
+    const typename MP::I cells = (typename MP::I)(base + gp->off_cells);
+    const typename MP::D P = (typename MP::D)(base + gp->off_p), V = (typename MP::D)(base + gp->off_v);
+    const double bx = gp->bmin[0], by = gp->bmin[1], bz = gp->bmin[2], ix = gp->inv[0], iy = gp->inv[1], iz = gp->inv[2];
+    const double cwy = gp->cw[1], cwz = gp->cw[2];
+    const int gx = gp->g[0], gy = gp->g[1], gz = gp->g[2];
     const d3 m = brdf_remap(wo, wi);
-    double max_dist = .01;
-    for (;;) {
-        const double r2 = max_dist * max_dist, rp = max_dist * (1. + 1e-9) + 1e-12;
-        const int x0 = grid_cell(m.x - rp, g.bmin[0], g.inv[0], g.g[0]), x1 = grid_cell(m.x + rp, g.bmin[0], g.inv[0], g.g[0]);
-        const int y0 = grid_cell(m.y - rp, g.bmin[1], g.inv[1], g.g[1]), y1 = grid_cell(m.y + rp, g.bmin[1], g.inv[1], g.g[1]);
-        const int z0 = grid_cell(m.z - rp, g.bmin[2], g.inv[2], g.g[2]), z1 = grid_cell(m.z + rp, g.bmin[2], g.inv[2], g.g[2]);
-        int cnt = 0;
+    int k = ((typename MP::I)(base + gp->off_kstart))[(grid_cell(m.z, bz, iz, gz) * gy + grid_cell(m.y, by, iy, gy)) * gx +
+                                                      grid_cell(m.x, bx, ix, gx)];
+    for (;; k++) {
+        const double max_dist = gp->radius[k];
+        // rp: the radius padded by more than the rounding of the cell assignment, for the choice of cells only
+        const double r2 = max_dist * max_dist, rp = max_dist * (1. + 1e-9) + 1e-12, rp2 = rp * rp;
+        const int y0 = grid_cell(m.y - rp, by, iy, gy), y1 = grid_cell(m.y + rp, by, iy, gy);
+        const int z1 = grid_cell(m.z + rp, bz, iz, gz);
+        int cnt = 0, nlist = 0;
         double sum_wt = 0.;
         d3 v = mk3(0, 0, 0);
-        for (int z = z0; z <= z1; z++)
+        for (int z = grid_cell(m.z - rp, bz, iz, gz); z <= z1; z++) {
+            const double dz = interval_dist(m.z, bz + z * cwz, bz + (z + 1) * cwz);
             for (int y = y0; y <= y1; y++) {
-                const int row = (z * g.g[1] + y) * g.g[0];
-                const int e = g.cells[row + x1 + 1];
-                for (int i = g.cells[row + x0]; i < e; i++) {
-                    const d3 d = mk3(g.p[3 * i], g.p[3 * i + 1], g.p[3 * i + 2]) - m;
+                const double dy = interval_dist(m.y, by + y * cwy, by + (y + 1) * cwy);
+                const double h2 = rp2 - dz * dz - dy * dy;
+                if (!(h2 >= 0.)) continue;       // the ball misses this row of cells
+                const double h = sqrt(h2) * (1. + 1e-9) + 1e-12;
+                const int row = (z * gy + y) * gx;
+                const int e = cells[row + grid_cell(m.x + h, bx, ix, gx) + 1];
+                for (int i = cells[row + grid_cell(m.x - h, bx, ix, gx)]; i < e; i++) {
+                    const d3 d = mk3(P[3 * i], P[3 * i + 1], P[3 * i + 2]) - m;
                     const double d2 = d.x * d.x + d.y * d.y + d.z * d.z;
                     if (d2 <= r2) {
-                        const double wt = exp(d2 * -100.);
                         cnt++;
-                        sum_wt += wt;
-                        v = v + mk3(g.v[3 * i], g.v[3 * i + 1], g.v[3 * i + 2]) * wt;
+                        if (nlist == PT_MEAS_HITS) {     // a dense ball: weight what is listed, go on listing
+                            measured_flush<LDS>(P, V, m, hits, nlist, sum_wt, v);
+                            nlist = 0;
+                        }
+                        hits[nlist++ * PT_MEAS_STRIDE] = i;
                     }
                 }
             }
-        if (cnt > 2 || max_dist > 1.5) return mk3(max0(v.x), max0(v.y), max0(v.z)) / sum_wt;   // v.clip() / sum_wt
-        max_dist *= 1.414;
+        }
+        if (cnt > 2 || max_dist > 1.5) {
+            measured_flush<LDS>(P, V, m, hits, nlist, sum_wt, v);
+            return mk3(max0(v.x), max0(v.y), max0(v.z)) / sum_wt;   // v.clip() / sum_wt
+        }
     }
+}
+__device__ inline d3 measured_f(const char *base, bool in_lds, int table, d3 wo, d3 wi, int *hits) {
+    return in_lds ? measured_f_as<true>(base, table, wo, wi, hits) : measured_f_as<false>(base, table, wo, wi, hits);
 }
 
 // EXT (here and below): the shade kernels that scenes with measured lobes run (k_shade<KIND, 2>, pt_launch_shade);
 // the measured lobe is compiled into those only, so that the other kernels keep their registers
 template <bool EXT>
-__device__ inline d3 lobe_f(const pt_lobe &l, d3 wo, d3 wi, const BrdfGrid *brdf) {
+__device__ inline d3 lobe_f(const pt_lobe &l, d3 wo, d3 wi, const Vertex &vx) {
     d3 R = mk3(l.R[0], l.R[1], l.R[2]);
-    if (EXT && l.type == PT_LOBE_MEASURED_IRISO) return measured_f(brdf[(int)l.a], wo, wi);
+    if (EXT && l.type == PT_LOBE_MEASURED_IRISO) return measured_f(vx.brdf, vx.brdf_in_lds, (int)l.a, wo, wi, vx.hits);
     switch (l.type) {
     case PT_LOBE_LAMBERT:   // bdf.py:327-332
         return R * PT_INV_PI;
@@ -461,7 +548,7 @@ __device__ inline double lobe_pdf(const pt_lobe &l, d3 wo, d3 wi) {
 
 template <bool EXT>
 __device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, double u2, d3 &wi_out, d3 &f_out,
-                                       const BrdfGrid *brdf) {
+                                       const Vertex &vx) {
     d3 R = mk3(l.R[0], l.R[1], l.R[2]);
     switch (l.type) {
     case PT_LOBE_LAMBERT:
@@ -477,7 +564,7 @@ __device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, doubl
         wi.z = sqrt(max0(1. - wi.x * wi.x - wi.y * wi.y));
         if (wo.z < 0.) wi.z *= -1.;
         wi_out = wi;
-        f_out = lobe_f<EXT>(l, wo, wi, brdf);
+        f_out = lobe_f<EXT>(l, wo, wi, vx);
         return lobe_pdf(l, wo, wi);
     }
     case PT_LOBE_MICROFACET_BLINN:
@@ -495,7 +582,7 @@ __device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, doubl
         if (dwh <= 0.) pdf = 0.;
         wi_out = wi;
         if (wi.z * wo.z <= 0.) f_out = mk3(0, 0, 0);
-        else f_out = lobe_f<EXT>(l, wo, wi, brdf);
+        else f_out = lobe_f<EXT>(l, wo, wi, vx);
         return pdf;
     }
     case PT_LOBE_SPEC_REFLECT: {   // bdf.py:251-256
@@ -531,7 +618,7 @@ __device__ inline d3 bsdf_f(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned flags) 
     else flags &= ~BDF_REFLECTION;
     d3 f = mk3(0, 0, 0);
     for (int i = 0; i < vx.mat->n_lobes; i++)
-        if (match_flag(vx.mat->lobes[i].type, flags)) f = f + lobe_f<EXT>(vx.mat->lobes[i], wo, wi, vx.brdf);
+        if (match_flag(vx.mat->lobes[i].type, flags)) f = f + lobe_f<EXT>(vx.mat->lobes[i], wo, wi, vx);
     return f;
 }
 
@@ -578,7 +665,7 @@ __device__ inline d3 bsdf_f_pdf(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned fla
             if (dwh > 0.) pdf += ((l.c + 1.) * pw) / (2. * PT_PI * 4. * dwh);
             continue;
         }
-        if (mf) f = f + lobe_f<EXT>(l, wo, wi, vx.brdf);
+        if (mf) f = f + lobe_f<EXT>(l, wo, wi, vx);
         if (mp) { n_match++; pdf += lobe_pdf(l, wo, wi); }
     }
     pdf_out = n_match > 0 ? pdf / n_match : 0.;
@@ -606,7 +693,7 @@ __device__ inline double bsdf_sample_f(const Vertex &vx, d3 wo_w, double u0, dou
         }
     if (pick < 0) return 0.;
     d3 wo = w2l(vx, wo_w), wi, fl;
-    double pdf = lobe_sample_f<EXT>(m->lobes[pick], wo, u0, u1, wi, fl, vx.brdf);
+    double pdf = lobe_sample_f<EXT>(m->lobes[pick], wo, u0, u1, wi, fl, vx);
     if (pdf == 0.) return 0.;
     wi_w = l2w(vx, wi);
     if (n_match > 1) pdf /= n_match;

@@ -5,6 +5,7 @@
 #include "pt_device.h"
 
 #define PT_BLOCK 256   // 4 waves of 64 lanes
+static_assert(PT_BLOCK == PT_MEAS_STRIDE, "hit lists of measured_f are strided by the shade block size");
 #define PT_MAX_DEVICES 64   // devices one process can hold contexts on (per-device launch attributes)
 #define PT_CNT_SHARDS 256
 
