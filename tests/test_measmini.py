@@ -189,3 +189,32 @@ def test_gpu_c5_workload_matches_oracle(ctx, golden_dir):
     x, y = sg.as_dict(), so.as_dict()
     for k in ('camera_samples', 'rays_closest', 'rays_any', 'guard_nan', 'guard_neg', 'guard_inf'):
         assert x[k] == y[k], (k, x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_samples', [2, 3, 5000])
+def test_gpu_table_sizes(ctx, golden_dir, n_samples):
+    """Tables the LDS copy cannot hold (5000 samples = 240 KB: the walk runs from HBM) and tables of 2 or 3 samples
+    (2: every ball grows past 1.5 and takes both samples, measured.py:56; 3: the first ball that reaches all three):
+    device == oracle on a small C5-like render."""
+    import os
+    import torch
+    from pytracer_amd import host, workloads
+    flat = workloads.c5_head_measured(os.path.join(golden_dir, 'head_mesh_scene.npz'), n_samples=n_samples, seed=11)
+    assert len(flat.brdf_p) == n_samples
+    ctx.upload(flat)
+    cam, film = host.head_mesh_camera_film(32, 32)
+    smp = pa.sampler_desc(0, 32, 0, 32, 2, 2, True, 5)
+    tile = pa.tile_desc(0, 32, 0, 32, 0, 4)
+    integ = pa.integrator_desc(A.PT_INTEG_PATH, 5, False)
+    acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
+    sg, so = A.pt_stats(), A.pt_stats()
+    ctx.render(cam, film, smp, integ, tile, acc, stats=sg)
+    torch.cuda.synchronize()
+    oacc, _ = O.OracleScene(flat).render(cam, film, smp, integ, tile, stats=so, want_L=False)
+    a = acc.cpu().numpy()
+    assert np.isfinite(a).all() and np.abs(oacc).max() > 0
+    assert np.abs(a - oacc).max() <= 1e-6 * np.abs(oacc).max()       # tolerance: see test_gpu_c5_workload_matches_oracle
+    x, y = sg.as_dict(), so.as_dict()
+    for k in ('camera_samples', 'rays_closest', 'rays_any', 'guard_nan', 'guard_neg', 'guard_inf'):
+        assert x[k] == y[k], (k, x, y)

@@ -27,9 +27,9 @@ def short(name):
     m = re.match(r'(?:void )?k_trace_(?:meta|top)<(true|false)>', name)   # LDS-staged variants of the same walk
     if m:
         return 'k_trace<%s>' % ('any' if m.group(1) == 'true' else 'closest')
-    m = re.match(r'(?:void )?k_shade<(\d+), (true|false)>', name)         # second argument: textured scene
+    m = re.match(r'(?:void )?k_shade<(\d+), (\d+|true|false)>', name)    # second argument: 1 textures / uvs, 2 measured BRDF
     if m:
-        return 'k_shade<%s>%s' % (m.group(1), '+tex' if m.group(2) == 'true' else '')
+        return 'k_shade<%s>%s' % (m.group(1), {'1': '+tex', 'true': '+tex', '2': '+meas'}.get(m.group(2), ''))
     m = re.match(r'(?:void )?(k_[a-z_]+)(<\d+>)?', name)
     return (m.group(1) + (m.group(2) or '')) if m else name[:60]
 
