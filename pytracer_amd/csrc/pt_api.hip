@@ -232,6 +232,12 @@ static hipError_t upload(void **dst, const T *src, size_t count) {
     return e;
 }
 
+// rounds added to the per-cell guess of the measured BRDF walk (PT_MEAS_GUESS_BIAS, tuning only: results do not depend on it)
+static int pt_meas_guess_bias() {
+    const char *e = getenv("PT_MEAS_GUESS_BIAS");
+    return e ? atoi(e) : 0;      // measured on the C5 workload: shade 208 / 226 / 295 ms per step for 0 / +1 / +2
+}
+
 extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     if (!c || !d) return PT_ERR_ARG;
     if (d->n_nodes < 0 || d->n_tris < 0 || d->n_materials < 0 || d->n_lights < 0) return fail(c, PT_ERR_ARG, "negative count");
@@ -371,7 +377,8 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
             std::vector<BrdfGrid> grids(tables.size());
             for (size_t t = 0; t < tables.size(); t++) {
                 const int64_t n = tables[t].second;
-                int g = (int)ceil(cbrt((double)n / 2.));
+                const char *e_per = getenv("PT_MEAS_CELL_SAMPLES");      // tuning only: samples per grid cell
+                int g = (int)ceil(cbrt((double)n / (e_per && atof(e_per) > 0. ? atof(e_per) : 2.)));
                 g = std::min(std::max(g, 1), 32);
                 grids[t].n = (int32_t)n;
                 for (int k = 0; k < 3; k++) grids[t].g[k] = g;
@@ -386,7 +393,7 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
             HIPCHK(c, hipMalloc(&c->d_brdf, blob.size()));
             double *pv = (double *)(blob.data() + off_pv);
             int32_t *cells = (int32_t *)(blob.data() + off_cells);
-            int32_t *kstart = (int32_t *)(blob.data() + off_k);
+            int32_t *kguess = (int32_t *)(blob.data() + off_k);
             size_t pos = 0, cpos = 0;
             for (size_t t = 0; t < tables.size(); t++) {
                 BrdfGrid &G = grids[t];
@@ -432,32 +439,25 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
                 G.off_p = (int32_t)(off_pv + pos * 6 * sizeof(double));
                 G.off_v = G.off_p + (int32_t)((size_t)n * 3 * sizeof(double));
                 G.off_cells = (int32_t)(off_cells + cpos * sizeof(int32_t));
-                G.off_kstart = (int32_t)(off_k + cpos * sizeof(int32_t));
+                G.off_kguess = (int32_t)(off_k + cpos * sizeof(int32_t));
                 // the radii of measured.py:53,66, by the same multiplications; radius[15] = 1.81 is the first > 1.5
                 G.radius[0] = .01;
                 for (int k = 1; k < 16; k++) G.radius[k] = G.radius[k - 1] * 1.414;
-                // kstart[cell]: a ball around ANY point of the cell (border cells reach to infinity outwards: queries
-                // outside the box are clamped into them) holds 3 samples only if its radius reaches the third
-                // smallest sample-to-box distance.  Samples within W cells are examined; one beyond is at least W
-                // cell widths away.
+                // kguess[cell]: the round at which a query at the cell's centre would end = the first radius that
+                // reaches the third-nearest sample; the samples within W cells are examined (beyond: W cell widths).
+                // Only a starting point for measured_f's phase 1, which corrects it.
                 {
                     const int W = 2;
-                    double cw_min = INFINITY, cw_max = 0.;
+                    double cw_min = INFINITY;
                     for (int k = 0; k < 3; k++)
-                        if (G.cw[k] > 0.) {
-                            cw_min = std::min(cw_min, G.cw[k]);
-                            cw_max = std::max(cw_max, G.cw[k]);
-                        }
-                    int32_t *ks = kstart + cpos;
+                        if (G.cw[k] > 0.) cw_min = std::min(cw_min, G.cw[k]);
+                    int32_t *ks = kguess + cpos;
                     for (int cz = 0; cz < G.g[2]; cz++)
                         for (int cy = 0; cy < G.g[1]; cy++)
                             for (int cx = 0; cx < G.g[0]; cx++) {
                                 const int ci[3] = {cx, cy, cz};
-                                double lo[3], hi[3];
-                                for (int k = 0; k < 3; k++) {
-                                    lo[k] = ci[k] == 0 ? -INFINITY : G.bmin[k] + ci[k] * G.cw[k];
-                                    hi[k] = ci[k] == G.g[k] - 1 ? INFINITY : G.bmin[k] + (ci[k] + 1) * G.cw[k];
-                                }
+                                double ctr[3];
+                                for (int k = 0; k < 3; k++) ctr[k] = G.bmin[k] + (ci[k] + .5) * G.cw[k];
                                 double best[3] = {INFINITY, INFINITY, INFINITY};     // three smallest squared distances
                                 for (int z = std::max(cz - W, 0); z <= std::min(cz + W, G.g[2] - 1); z++)
                                     for (int y = std::max(cy - W, 0); y <= std::min(cy + W, G.g[1] - 1); y++) {
@@ -465,8 +465,7 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
                                         for (int32_t i = cs[row + std::max(cx - W, 0)]; i < cs[row + std::min(cx + W, G.g[0] - 1) + 1]; i++) {
                                             double d2 = 0.;
                                             for (int k = 0; k < 3; k++) {
-                                                const double q = p_out[3 * (size_t)i + k];
-                                                const double dd = q < lo[k] ? lo[k] - q : (q > hi[k] ? q - hi[k] : 0.);
+                                                const double dd = p_out[3 * (size_t)i + k] - ctr[k];
                                                 d2 += dd * dd;
                                             }
                                             if (d2 < best[2]) {
@@ -476,11 +475,10 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
                                             }
                                         }
                                     }
-                                double bound = std::min(sqrt(best[2]), W * cw_min);
-                                bound = bound * (1. - 1e-9) - 1e-9 * cw_max;      // rounding of the cell assignment
+                                const double d3 = std::min(sqrt(best[2]), (W + .5) * cw_min);
                                 int k0 = 0;
-                                while (k0 < 15 && G.radius[k0] < bound) k0++;
-                                ks[((size_t)cz * G.g[1] + cy) * G.g[0] + cx] = k0;
+                                while (k0 < 15 && !(G.radius[k0] >= d3)) k0++;
+                                ks[((size_t)cz * G.g[1] + cy) * G.g[0] + cx] = std::max(std::min(k0 + pt_meas_guess_bias(), 15), 0);
                             }
                 }
                 pos += (size_t)n;
@@ -520,7 +518,7 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     s.tex_scratch = (pt_material *)c->d_tex_scratch;
     s.tri_uv = (const double *)c->d_uv;
     s.brdf = (const char *)c->d_brdf;
-    s.brdf_lds_bytes = (c->d_brdf && c->brdf_bytes + PT_MEAS_HITS * PT_BLOCK * sizeof(int) <= (size_t)64 * 1024 && !getenv("PT_BRDF_NO_LDS")) ? (int32_t)c->brdf_bytes : 0;
+    s.brdf_lds_bytes = (c->d_brdf && c->brdf_bytes + PT_MEAS_HITS * PT_BLOCK * sizeof(int) <= (size_t)PT_MEAS_LDS_MAX && !getenv("PT_BRDF_NO_LDS")) ? (int32_t)c->brdf_bytes : 0;
     s.n_nodes = d->n_nodes; s.n_tris = d->n_tris; s.n_mats = d->n_materials; s.n_lights = d->n_lights;
     memcpy(s.le_sum, le, sizeof(le));
     c->stack_need = std::max(depth, 1);

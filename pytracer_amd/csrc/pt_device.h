@@ -107,7 +107,7 @@ struct BrdfGrid {
     double radius[16];         // .01 * 1.414^k as the reference's loop produces them (radius[15] is the first > 1.5)
     int32_t g[3], n;
     int32_t off_cells;         // int32 [g0*g1*g2 + 1] first sample of every cell
-    int32_t off_kstart;        // int32 [g0*g1*g2] the first k at which a ball around a point of the cell CAN hold 3 samples
+    int32_t off_kguess;        // int32 [g0*g1*g2] the round at which a query at the cell's centre ends (a guess, not a bound)
     int32_t off_p, off_v;      // double [n][3] sample positions (brdf_remap space) and RGB values, in cell order
 };
 
@@ -378,10 +378,8 @@ __device__ __forceinline__ int grid_cell(double x, double bmin, double inv, int 
 }
 // IrIsotropicBRDF.f, reflection/bdf/measured.py:51-66: the ball around m grows from .01 by 1.414 until it holds
 // more than two samples or its radius exceeds 1.5; the result is the mean of the samples in it, weighted
-// exp(-100 d^2).  query_ball_point (cKDTree, p = 2) = squared distance <= r*r.  Here the samples come from the grid:
-// per (y, z) row of cells the ball's chord gives the x range (rows the ball misses are skipped), every sample in it
-// is tested exactly, and the sums run in cell order.  The radii below kstart cannot succeed anywhere in m's cell
-// (a bound computed at upload from the distances of the samples to the cell's box), so the loop starts there.
+// exp(-100 d^2).  query_ball_point (cKDTree, p = 2) = squared distance <= r*r.  Here the samples come from the grid,
+// every candidate is tested exactly, and the sums run in cell order.
 __device__ __forceinline__ double interval_dist(double x, double lo, double hi) {
     return x < lo ? lo - x : (x > hi ? x - hi : 0.);
 }
@@ -391,7 +389,8 @@ __device__ __forceinline__ double interval_dist(double x, double lo, double hi) 
 // max-over-lanes(samples in the ball) times per wave instead of once per scan step (some lane is inside its ball at
 // nearly every step).  Tried and rejected: one flat loop in which a lane either tests a candidate or steps to its
 // next row (rows hold 2-5 candidates, so the ~100-instruction row set-up ran at every step: shade 363 -> 497 ms).
-#define PT_MEAS_HITS 12
+#define PT_MEAS_HITS 24
+#define PT_MEAS_LDS_MAX (78 * 1024)   // dynamic LDS of k_shade<KIND, 2>: hit lists + table blob; two blocks per CU (160 KB)
 #define PT_MEAS_STRIDE 256   // = PT_BLOCK (pt_kernels.h checks): entry j of a thread's list is hits[j * PT_MEAS_STRIDE]
 // Pointer types of the blob: explicit LDS pointers (ds_read with 32-bit addresses) when k_shade staged it, else
 // global memory.  Through generic pointers every access is a flat instruction with 64-bit address arithmetic.
@@ -412,11 +411,12 @@ typedef PT_AS_LDS int *lds_int_ptr;
 
 template <bool LDS>
 __device__ __forceinline__ void measured_flush(typename MeasPtr<LDS>::D P, typename MeasPtr<LDS>::D V, d3 m, lds_int_ptr hits, int n,
-                                               double &sum_wt, d3 &v) {
+                                               double r2, double &sum_wt, d3 &v) {
     for (int j = 0; j < n; j++) {
         const int i = hits[j * PT_MEAS_STRIDE];
         const d3 d = mk3(P[3 * i], P[3 * i + 1], P[3 * i + 2]) - m;
         const double d2 = d.x * d.x + d.y * d.y + d.z * d.z;
+        if (!(d2 <= r2)) continue;           // a list made at a larger radius (phase 1)
 #if PT_MEAS_ABL == 3
         const double wt = 1. - d2;
 #else
@@ -426,6 +426,41 @@ __device__ __forceinline__ void measured_flush(typename MeasPtr<LDS>::D P, typen
         v = v + mk3(V[3 * i], V[3 * i + 1], V[3 * i + 2]) * wt;
     }
 }
+// One pass over the cells around m at radius r: visits every sample in the (y, z) rows of cells the ball touches,
+// within the x range of the ball's chord in that row (padded by more than the rounding of the cell assignment), so
+// every sample with d^2 <= r^2 is visited, some others too.  `visit(i, d2)` gets the sample index and its squared distance.
+template <bool LDS, class F>
+__device__ __forceinline__ void measured_scan(typename MeasPtr<LDS>::G gp, typename MeasPtr<LDS>::I cells, typename MeasPtr<LDS>::D P,
+                                              d3 m, double r, F visit) {
+    const double bx = gp->bmin[0], by = gp->bmin[1], bz = gp->bmin[2], ix = gp->inv[0], iy = gp->inv[1], iz = gp->inv[2];
+    const double cwy = gp->cw[1], cwz = gp->cw[2];
+    const int gx = gp->g[0], gy = gp->g[1], gz = gp->g[2];
+    const double rp = r * (1. + 1e-9) + 1e-12, rp2 = rp * rp;
+    const int y0 = grid_cell(m.y - rp, by, iy, gy), y1 = grid_cell(m.y + rp, by, iy, gy);
+    const int z1 = grid_cell(m.z + rp, bz, iz, gz);
+    for (int z = grid_cell(m.z - rp, bz, iz, gz); z <= z1; z++) {
+        const double dz = interval_dist(m.z, bz + z * cwz, bz + (z + 1) * cwz);
+        for (int y = y0; y <= y1; y++) {
+            const double dy = interval_dist(m.y, by + y * cwy, by + (y + 1) * cwy);
+            const double h2 = rp2 - dz * dz - dy * dy;
+            if (!(h2 >= 0.)) continue;       // the ball misses this row of cells
+            const double h = sqrt(h2) * (1. + 1e-9) + 1e-12;
+            const int row = (z * gy + y) * gx;
+            const int e = cells[row + grid_cell(m.x + h, bx, ix, gx) + 1];
+            for (int i = cells[row + grid_cell(m.x - h, bx, ix, gx)]; i < e; i++) {
+                const d3 d = mk3(P[3 * i], P[3 * i + 1], P[3 * i + 2]) - m;
+                visit(i, d.x * d.x + d.y * d.y + d.z * d.z);
+            }
+        }
+    }
+}
+
+// The reference's loop (ball radius .01, x 1.414 per round, until more than 2 samples are inside or the radius
+// exceeds 1.5) ends at the first radius that reaches the THIRD-NEAREST sample.  So instead of one scan per round:
+// phase 1 finds the squared distance of the third-nearest sample with one branch-free scan at a guessed radius
+// (kguess of m's cell, computed at upload; the scan is repeated one round further out in the rare case that the guess
+// holds fewer than 3 samples), which gives the round kf the reference stops at by the same `d2 <= r*r` comparisons;
+// phase 2 scans ball kf once, lists its samples and weights them.
 template <bool LDS>
 __device__ inline d3 measured_f_as(const char *base_generic, int table, d3 wo, d3 wi, int *hits_generic) {
 #if PT_MEAS_ABL == 1
@@ -437,49 +472,58 @@ __device__ inline d3 measured_f_as(const char *base_generic, int table, d3 wo, d
     const typename MP::G gp = (typename MP::G)base + table;
     const typename MP::I cells = (typename MP::I)(base + gp->off_cells);
     const typename MP::D P = (typename MP::D)(base + gp->off_p), V = (typename MP::D)(base + gp->off_v);
-    const double bx = gp->bmin[0], by = gp->bmin[1], bz = gp->bmin[2], ix = gp->inv[0], iy = gp->inv[1], iz = gp->inv[2];
-    const double cwy = gp->cw[1], cwz = gp->cw[2];
-    const int gx = gp->g[0], gy = gp->g[1], gz = gp->g[2];
     const d3 m = brdf_remap(wo, wi);
-    int k = ((typename MP::I)(base + gp->off_kstart))[(grid_cell(m.z, bz, iz, gz) * gy + grid_cell(m.y, by, iy, gy)) * gx +
-                                                      grid_cell(m.x, bx, ix, gx)];
-    for (;; k++) {
-        const double max_dist = gp->radius[k];
-        // rp: the radius padded by more than the rounding of the cell assignment, for the choice of cells only
-        const double r2 = max_dist * max_dist, rp = max_dist * (1. + 1e-9) + 1e-12, rp2 = rp * rp;
-        const int y0 = grid_cell(m.y - rp, by, iy, gy), y1 = grid_cell(m.y + rp, by, iy, gy);
-        const int z1 = grid_cell(m.z + rp, bz, iz, gz);
-        int cnt = 0, nlist = 0;
-        double sum_wt = 0.;
-        d3 v = mk3(0, 0, 0);
-        for (int z = grid_cell(m.z - rp, bz, iz, gz); z <= z1; z++) {
-            const double dz = interval_dist(m.z, bz + z * cwz, bz + (z + 1) * cwz);
-            for (int y = y0; y <= y1; y++) {
-                const double dy = interval_dist(m.y, by + y * cwy, by + (y + 1) * cwy);
-                const double h2 = rp2 - dz * dz - dy * dy;
-                if (!(h2 >= 0.)) continue;       // the ball misses this row of cells
-                const double h = sqrt(h2) * (1. + 1e-9) + 1e-12;
-                const int row = (z * gy + y) * gx;
-                const int e = cells[row + grid_cell(m.x + h, bx, ix, gx) + 1];
-                for (int i = cells[row + grid_cell(m.x - h, bx, ix, gx)]; i < e; i++) {
-                    const d3 d = mk3(P[3 * i], P[3 * i + 1], P[3 * i + 2]) - m;
-                    const double d2 = d.x * d.x + d.y * d.y + d.z * d.z;
-                    if (d2 <= r2) {
-                        cnt++;
-                        if (nlist == PT_MEAS_HITS) {     // a dense ball: weight what is listed, go on listing
-                            measured_flush<LDS>(P, V, m, hits, nlist, sum_wt, v);
-                            nlist = 0;
-                        }
-                        hits[nlist++ * PT_MEAS_STRIDE] = i;
-                    }
-                }
+    int kg = ((typename MP::I)(base + gp->off_kguess))[
+        (grid_cell(m.z, gp->bmin[2], gp->inv[2], gp->g[2]) * gp->g[1] + grid_cell(m.y, gp->bmin[1], gp->inv[1], gp->g[1])) * gp->g[0] +
+        grid_cell(m.x, gp->bmin[0], gp->inv[0], gp->g[0])];
+    // phase 1: a0 <= a1 <= a2 = the three smallest squared distances among the visited samples; once a2 <= r_kg^2
+    // they are the three smallest of the whole table (an unvisited sample lies outside ball kg).  The samples inside
+    // ball kg are listed on the way: ball kf lies inside it, so if the list did not overflow phase 2 needs no scan.
+    double a2;
+    int nl;
+    for (;; kg++) {
+        const double r = gp->radius[kg], r2g = r * r;
+        double a0 = __builtin_inf(), a1 = __builtin_inf();
+        a2 = __builtin_inf();
+        nl = 0;
+        measured_scan<LDS>(gp, cells, P, m, r, [&](int i, double d2) {
+            if (d2 <= r2g) {
+                if (nl < PT_MEAS_HITS) hits[nl * PT_MEAS_STRIDE] = i;
+                nl++;
             }
-        }
-        if (cnt > 2 || max_dist > 1.5) {
-            measured_flush<LDS>(P, V, m, hits, nlist, sum_wt, v);
-            return mk3(max0(v.x), max0(v.y), max0(v.z)) / sum_wt;   // v.clip() / sum_wt
-        }
+            double t = d2 == d2 ? d2 : __builtin_inf();      // a NaN query never counts a sample
+            const double l0 = fmin(a0, t);
+            t = fmax(a0, t);
+            a0 = l0;
+            const double l1 = fmin(a1, t);
+            t = fmax(a1, t);
+            a1 = l1;
+            a2 = fmin(a2, t);
+        });
+        if (a2 <= r2g || r > 1.5) break;             // radius[15] is the first > 1.5
     }
+    int kf = 0;
+    while (!(a2 <= gp->radius[kf] * gp->radius[kf]) && !(gp->radius[kf] > 1.5)) kf++;
+    // phase 2: the samples of ball kf (kf <= kg), weighted in cell order
+    const double max_dist = gp->radius[kf], r2 = max_dist * max_dist;
+    double sum_wt = 0.;
+    d3 v = mk3(0, 0, 0);
+    if (nl <= PT_MEAS_HITS) {
+        measured_flush<LDS>(P, V, m, hits, nl, r2, sum_wt, v);
+    } else {                                 // more than a list of samples in ball kg: scan ball kf
+        int nlist = 0;
+        measured_scan<LDS>(gp, cells, P, m, max_dist, [&](int i, double d2) {
+            if (d2 <= r2) {
+                if (nlist == PT_MEAS_HITS) {     // a dense ball: weight what is listed, go on listing
+                    measured_flush<LDS>(P, V, m, hits, nlist, r2, sum_wt, v);
+                    nlist = 0;
+                }
+                hits[nlist++ * PT_MEAS_STRIDE] = i;
+            }
+        });
+        measured_flush<LDS>(P, V, m, hits, nlist, r2, sum_wt, v);
+    }
+    return mk3(max0(v.x), max0(v.y), max0(v.z)) / sum_wt;   // v.clip() / sum_wt
 }
 __device__ inline d3 measured_f(const char *base, bool in_lds, int table, d3 wo, d3 wi, int *hits) {
     return in_lds ? measured_f_as<true>(base, table, wo, wi, hits) : measured_f_as<false>(base, table, wo, wi, hits);

@@ -1018,6 +1018,19 @@ hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene 
                            int level, const Queue &qin, const HitList &hl, const Queue &qout, const ShadowQueue &sh,
                            const PathState &st) {
     grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
+    // the measured variants take up to PT_MEAS_LDS_MAX of dynamic LDS (hit lists + table blob): beyond the 64 KB a
+    // kernel gets by default, so the limit is raised once per device and kernel
+    static bool attr_set[PT_MAX_DEVICES][3];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (sc.brdf != nullptr && (kind == PT_INTEG_DIRECT || kind == PT_INTEG_PATH || kind == PT_INTEG_WHITTED) && !attr_set[dev][kind]) {
+        const void *fn = kind == PT_INTEG_DIRECT ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_DIRECT, 2>)
+                       : kind == PT_INTEG_WHITTED ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_WHITTED, 2>)
+                                                  : reinterpret_cast<const void *>(&k_shade<PT_INTEG_PATH, 2>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_MEAS_LDS_MAX);
+        if (e != hipSuccess) return e;
+        attr_set[dev][kind] = true;
+    }
 #define PT_SHADE(K, T) hipLaunchKernelGGL((k_shade<K, T>), dim3(grid), dim3(PT_BLOCK), (T) == 2 ? (size_t)sc.brdf_lds_bytes + PT_MEAS_HITS * PT_BLOCK * sizeof(int) : 0, stream, sc, rc, base, level, qin, hl, qout, sh, st)
     const int ext = sc.brdf != nullptr ? 2 : ((sc.textures != nullptr || sc.tri_uv != nullptr) ? 1 : 0);
 #define PT_SHADE_EXT(K) do { if (ext == 2) PT_SHADE(K, 2); else if (ext == 1) PT_SHADE(K, 1); else PT_SHADE(K, 0); } while (0)
