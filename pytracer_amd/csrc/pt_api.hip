@@ -238,6 +238,141 @@ static int pt_meas_guess_bias() {
     return e ? atoi(e) : 0;      // measured on the C5 workload: shade 208 / 226 / 295 ms per step for 0 / +1 / +2
 }
 
+// Measured BRDF tables (PT_LOBE_MEASURED_IRISO): one grid per distinct (first sample, count) range, all of them in
+// one device blob (BrdfGrid, pt_device.h).  `mats` is the copy of the materials that goes to the device: a measured
+// lobe's `a` becomes the index of its grid.  Ranges were validated by the caller.
+static int upload_brdf_tables(pt_ctx *c, const pt_scene_desc *d, std::vector<pt_material> &mats) {
+    std::vector<std::pair<int64_t, int64_t>> tables;
+    for (auto &m : mats)
+        for (int k = 0; k < m.n_lobes; k++)
+            if (m.lobes[k].type == PT_LOBE_MEASURED_IRISO) {
+                const std::pair<int64_t, int64_t> key((int64_t)m.lobes[k].a, (int64_t)m.lobes[k].b);
+                size_t t = 0;
+                while (t < tables.size() && tables[t] != key) t++;
+                if (t == tables.size()) tables.push_back(key);
+                m.lobes[k].a = (double)t;
+            }
+    if (!tables.empty()) {
+        // blob: [BrdfGrid x T][p, v doubles of all tables][cell starts of all tables][start rounds of all tables],
+        // addressed by byte offsets from its first byte so that k_shade can run it from an LDS copy
+        size_t n_all = 0, cells_all = 0;
+        std::vector<BrdfGrid> grids(tables.size());
+        for (size_t t = 0; t < tables.size(); t++) {
+            const int64_t n = tables[t].second;
+            const char *e_per = getenv("PT_MEAS_CELL_SAMPLES");      // tuning only: samples per grid cell
+            int g = (int)ceil(cbrt((double)n / (e_per && atof(e_per) > 0. ? atof(e_per) : 2.)));
+            g = std::min(std::max(g, 1), 32);
+            grids[t].n = (int32_t)n;
+            for (int k = 0; k < 3; k++) grids[t].g[k] = g;
+            n_all += (size_t)n;
+            cells_all += (size_t)g * g * g + 1;
+        }
+        const size_t off_pv = grids.size() * sizeof(BrdfGrid), off_cells = off_pv + n_all * 6 * sizeof(double);
+        const size_t off_k = off_cells + cells_all * sizeof(int32_t);
+        const size_t blob_bytes = (off_k + cells_all * sizeof(int32_t) + 7) & ~(size_t)7;
+        if (blob_bytes > ((size_t)1 << 31) - 8) return fail(c, PT_ERR_CAPACITY, "measured BRDF tables exceed 2 GB");
+        std::vector<char> blob(blob_bytes);
+        HIPCHK(c, hipMalloc(&c->d_brdf, blob.size()));
+        double *pv = (double *)(blob.data() + off_pv);
+        int32_t *cells = (int32_t *)(blob.data() + off_cells);
+        int32_t *kguess = (int32_t *)(blob.data() + off_k);
+        size_t pos = 0, cpos = 0;
+        for (size_t t = 0; t < tables.size(); t++) {
+            BrdfGrid &G = grids[t];
+            const int64_t n = G.n;
+            const double *P = d->brdf_p + 3 * tables[t].first, *V = d->brdf_v + 3 * tables[t].first;
+            double bmax[3];
+            for (int k = 0; k < 3; k++) {
+                G.bmin[k] = n ? P[k] : 0.;
+                bmax[k] = G.bmin[k];
+            }
+            for (int64_t i = 0; i < n; i++)
+                for (int k = 0; k < 3; k++) {
+                    G.bmin[k] = std::min(G.bmin[k], P[3 * i + k]);
+                    bmax[k] = std::max(bmax[k], P[3 * i + k]);
+                }
+            for (int k = 0; k < 3; k++) {
+                const double ext = bmax[k] - G.bmin[k];
+                const bool ok = ext > 0. && std::isfinite(ext) && std::isfinite(G.bmin[k]) && std::isfinite(G.g[k] / ext);
+                G.inv[k] = ok ? G.g[k] / ext : 0.;
+                G.cw[k] = ok ? ext / G.g[k] : 0.;
+                if (!std::isfinite(G.bmin[k])) G.bmin[k] = 0.;
+            }
+            const size_t nc = (size_t)G.g[0] * G.g[1] * G.g[2];
+            auto cell_of = [&](const double *q) {
+                int ci[3];
+                for (int k = 0; k < 3; k++) {           // the same expression as grid_cell (pt_device.h)
+                    const double f = floor((q[k] - G.bmin[k]) * G.inv[k]);
+                    ci[k] = f >= (double)(G.g[k] - 1) ? G.g[k] - 1 : (f > 0. ? (int)f : 0);
+                }
+                return ((size_t)ci[2] * G.g[1] + ci[1]) * G.g[0] + ci[0];
+            };
+            int32_t *cs = cells + cpos;
+            std::fill(cs, cs + nc + 1, 0);
+            for (int64_t i = 0; i < n; i++) cs[cell_of(P + 3 * i) + 1]++;
+            for (size_t q = 0; q < nc; q++) cs[q + 1] += cs[q];
+            std::vector<int32_t> fill(cs, cs + nc);
+            double *p_out = pv + pos * 6, *v_out = p_out + (size_t)n * 3;
+            for (int64_t i = 0; i < n; i++) {
+                const int32_t at = fill[cell_of(P + 3 * i)]++;
+                memcpy(p_out + 3 * (size_t)at, P + 3 * i, 3 * sizeof(double));
+                memcpy(v_out + 3 * (size_t)at, V + 3 * i, 3 * sizeof(double));
+            }
+            G.off_p = (int32_t)(off_pv + pos * 6 * sizeof(double));
+            G.off_v = G.off_p + (int32_t)((size_t)n * 3 * sizeof(double));
+            G.off_cells = (int32_t)(off_cells + cpos * sizeof(int32_t));
+            G.off_kguess = (int32_t)(off_k + cpos * sizeof(int32_t));
+            // the radii of measured.py:53,66, by the same multiplications; radius[15] = 1.81 is the first > 1.5
+            G.radius[0] = .01;
+            for (int k = 1; k < 16; k++) G.radius[k] = G.radius[k - 1] * 1.414;
+            // kguess[cell]: the round at which a query at the cell's centre would end = the first radius that
+            // reaches the third-nearest sample; the samples within W cells are examined (beyond: W cell widths).
+            // Only a starting point for measured_f's phase 1, which corrects it.
+            {
+                const int W = 2;
+                double cw_min = INFINITY;
+                for (int k = 0; k < 3; k++)
+                    if (G.cw[k] > 0.) cw_min = std::min(cw_min, G.cw[k]);
+                int32_t *ks = kguess + cpos;
+                for (int cz = 0; cz < G.g[2]; cz++)
+                    for (int cy = 0; cy < G.g[1]; cy++)
+                        for (int cx = 0; cx < G.g[0]; cx++) {
+                            const int ci[3] = {cx, cy, cz};
+                            double ctr[3];
+                            for (int k = 0; k < 3; k++) ctr[k] = G.bmin[k] + (ci[k] + .5) * G.cw[k];
+                            double best[3] = {INFINITY, INFINITY, INFINITY};     // three smallest squared distances
+                            for (int z = std::max(cz - W, 0); z <= std::min(cz + W, G.g[2] - 1); z++)
+                                for (int y = std::max(cy - W, 0); y <= std::min(cy + W, G.g[1] - 1); y++) {
+                                    const size_t row = ((size_t)z * G.g[1] + y) * G.g[0];
+                                    for (int32_t i = cs[row + std::max(cx - W, 0)]; i < cs[row + std::min(cx + W, G.g[0] - 1) + 1]; i++) {
+                                        double d2 = 0.;
+                                        for (int k = 0; k < 3; k++) {
+                                            const double dd = p_out[3 * (size_t)i + k] - ctr[k];
+                                            d2 += dd * dd;
+                                        }
+                                        if (d2 < best[2]) {
+                                            best[2] = d2;
+                                            if (best[2] < best[1]) std::swap(best[1], best[2]);
+                                            if (best[1] < best[0]) std::swap(best[0], best[1]);
+                                        }
+                                    }
+                                }
+                            const double d3 = std::min(sqrt(best[2]), (W + .5) * cw_min);
+                            int k0 = 0;
+                            while (k0 < 15 && !(G.radius[k0] >= d3)) k0++;
+                            ks[((size_t)cz * G.g[1] + cy) * G.g[0] + cx] = std::max(std::min(k0 + pt_meas_guess_bias(), 15), 0);
+                        }
+            }
+            pos += (size_t)n;
+            cpos += nc + 1;
+        }
+        c->brdf_bytes = blob_bytes;
+        memcpy(blob.data(), grids.data(), off_pv);
+        HIPCHK(c, hipMemcpy(c->d_brdf, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    }
+    return PT_OK;
+}
+
 extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     if (!c || !d) return PT_ERR_ARG;
     if (d->n_nodes < 0 || d->n_tris < 0 || d->n_materials < 0 || d->n_lights < 0) return fail(c, PT_ERR_ARG, "negative count");
@@ -359,136 +494,8 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     // measured BRDF tables: one grid per distinct (first sample, count); the device copy of a measured lobe
     // carries the index of its grid in `a`
     std::vector<pt_material> mats(d->materials, d->materials + d->n_materials);
-    {
-        std::vector<std::pair<int64_t, int64_t>> tables;
-        for (auto &m : mats)
-            for (int k = 0; k < m.n_lobes; k++)
-                if (m.lobes[k].type == PT_LOBE_MEASURED_IRISO) {
-                    const std::pair<int64_t, int64_t> key((int64_t)m.lobes[k].a, (int64_t)m.lobes[k].b);
-                    size_t t = 0;
-                    while (t < tables.size() && tables[t] != key) t++;
-                    if (t == tables.size()) tables.push_back(key);
-                    m.lobes[k].a = (double)t;
-                }
-        if (!tables.empty()) {
-            // blob: [BrdfGrid x T][p, v doubles of all tables][cell starts of all tables][start rounds of all tables],
-            // addressed by byte offsets from its first byte so that k_shade can run it from an LDS copy
-            size_t n_all = 0, cells_all = 0;
-            std::vector<BrdfGrid> grids(tables.size());
-            for (size_t t = 0; t < tables.size(); t++) {
-                const int64_t n = tables[t].second;
-                const char *e_per = getenv("PT_MEAS_CELL_SAMPLES");      // tuning only: samples per grid cell
-                int g = (int)ceil(cbrt((double)n / (e_per && atof(e_per) > 0. ? atof(e_per) : 2.)));
-                g = std::min(std::max(g, 1), 32);
-                grids[t].n = (int32_t)n;
-                for (int k = 0; k < 3; k++) grids[t].g[k] = g;
-                n_all += (size_t)n;
-                cells_all += (size_t)g * g * g + 1;
-            }
-            const size_t off_pv = grids.size() * sizeof(BrdfGrid), off_cells = off_pv + n_all * 6 * sizeof(double);
-            const size_t off_k = off_cells + cells_all * sizeof(int32_t);
-            const size_t blob_bytes = (off_k + cells_all * sizeof(int32_t) + 7) & ~(size_t)7;
-            if (blob_bytes > ((size_t)1 << 31) - 8) return fail(c, PT_ERR_CAPACITY, "measured BRDF tables exceed 2 GB");
-            std::vector<char> blob(blob_bytes);
-            HIPCHK(c, hipMalloc(&c->d_brdf, blob.size()));
-            double *pv = (double *)(blob.data() + off_pv);
-            int32_t *cells = (int32_t *)(blob.data() + off_cells);
-            int32_t *kguess = (int32_t *)(blob.data() + off_k);
-            size_t pos = 0, cpos = 0;
-            for (size_t t = 0; t < tables.size(); t++) {
-                BrdfGrid &G = grids[t];
-                const int64_t n = G.n;
-                const double *P = d->brdf_p + 3 * tables[t].first, *V = d->brdf_v + 3 * tables[t].first;
-                double bmax[3];
-                for (int k = 0; k < 3; k++) {
-                    G.bmin[k] = n ? P[k] : 0.;
-                    bmax[k] = G.bmin[k];
-                }
-                for (int64_t i = 0; i < n; i++)
-                    for (int k = 0; k < 3; k++) {
-                        G.bmin[k] = std::min(G.bmin[k], P[3 * i + k]);
-                        bmax[k] = std::max(bmax[k], P[3 * i + k]);
-                    }
-                for (int k = 0; k < 3; k++) {
-                    const double ext = bmax[k] - G.bmin[k];
-                    const bool ok = ext > 0. && std::isfinite(ext) && std::isfinite(G.bmin[k]) && std::isfinite(G.g[k] / ext);
-                    G.inv[k] = ok ? G.g[k] / ext : 0.;
-                    G.cw[k] = ok ? ext / G.g[k] : 0.;
-                    if (!std::isfinite(G.bmin[k])) G.bmin[k] = 0.;
-                }
-                const size_t nc = (size_t)G.g[0] * G.g[1] * G.g[2];
-                auto cell_of = [&](const double *q) {
-                    int ci[3];
-                    for (int k = 0; k < 3; k++) {           // the same expression as grid_cell (pt_device.h)
-                        const double f = floor((q[k] - G.bmin[k]) * G.inv[k]);
-                        ci[k] = f >= (double)(G.g[k] - 1) ? G.g[k] - 1 : (f > 0. ? (int)f : 0);
-                    }
-                    return ((size_t)ci[2] * G.g[1] + ci[1]) * G.g[0] + ci[0];
-                };
-                int32_t *cs = cells + cpos;
-                std::fill(cs, cs + nc + 1, 0);
-                for (int64_t i = 0; i < n; i++) cs[cell_of(P + 3 * i) + 1]++;
-                for (size_t q = 0; q < nc; q++) cs[q + 1] += cs[q];
-                std::vector<int32_t> fill(cs, cs + nc);
-                double *p_out = pv + pos * 6, *v_out = p_out + (size_t)n * 3;
-                for (int64_t i = 0; i < n; i++) {
-                    const int32_t at = fill[cell_of(P + 3 * i)]++;
-                    memcpy(p_out + 3 * (size_t)at, P + 3 * i, 3 * sizeof(double));
-                    memcpy(v_out + 3 * (size_t)at, V + 3 * i, 3 * sizeof(double));
-                }
-                G.off_p = (int32_t)(off_pv + pos * 6 * sizeof(double));
-                G.off_v = G.off_p + (int32_t)((size_t)n * 3 * sizeof(double));
-                G.off_cells = (int32_t)(off_cells + cpos * sizeof(int32_t));
-                G.off_kguess = (int32_t)(off_k + cpos * sizeof(int32_t));
-                // the radii of measured.py:53,66, by the same multiplications; radius[15] = 1.81 is the first > 1.5
-                G.radius[0] = .01;
-                for (int k = 1; k < 16; k++) G.radius[k] = G.radius[k - 1] * 1.414;
-                // kguess[cell]: the round at which a query at the cell's centre would end = the first radius that
-                // reaches the third-nearest sample; the samples within W cells are examined (beyond: W cell widths).
-                // Only a starting point for measured_f's phase 1, which corrects it.
-                {
-                    const int W = 2;
-                    double cw_min = INFINITY;
-                    for (int k = 0; k < 3; k++)
-                        if (G.cw[k] > 0.) cw_min = std::min(cw_min, G.cw[k]);
-                    int32_t *ks = kguess + cpos;
-                    for (int cz = 0; cz < G.g[2]; cz++)
-                        for (int cy = 0; cy < G.g[1]; cy++)
-                            for (int cx = 0; cx < G.g[0]; cx++) {
-                                const int ci[3] = {cx, cy, cz};
-                                double ctr[3];
-                                for (int k = 0; k < 3; k++) ctr[k] = G.bmin[k] + (ci[k] + .5) * G.cw[k];
-                                double best[3] = {INFINITY, INFINITY, INFINITY};     // three smallest squared distances
-                                for (int z = std::max(cz - W, 0); z <= std::min(cz + W, G.g[2] - 1); z++)
-                                    for (int y = std::max(cy - W, 0); y <= std::min(cy + W, G.g[1] - 1); y++) {
-                                        const size_t row = ((size_t)z * G.g[1] + y) * G.g[0];
-                                        for (int32_t i = cs[row + std::max(cx - W, 0)]; i < cs[row + std::min(cx + W, G.g[0] - 1) + 1]; i++) {
-                                            double d2 = 0.;
-                                            for (int k = 0; k < 3; k++) {
-                                                const double dd = p_out[3 * (size_t)i + k] - ctr[k];
-                                                d2 += dd * dd;
-                                            }
-                                            if (d2 < best[2]) {
-                                                best[2] = d2;
-                                                if (best[2] < best[1]) std::swap(best[1], best[2]);
-                                                if (best[1] < best[0]) std::swap(best[0], best[1]);
-                                            }
-                                        }
-                                    }
-                                const double d3 = std::min(sqrt(best[2]), (W + .5) * cw_min);
-                                int k0 = 0;
-                                while (k0 < 15 && !(G.radius[k0] >= d3)) k0++;
-                                ks[((size_t)cz * G.g[1] + cy) * G.g[0] + cx] = std::max(std::min(k0 + pt_meas_guess_bias(), 15), 0);
-                            }
-                }
-                pos += (size_t)n;
-                cpos += nc + 1;
-            }
-            c->brdf_bytes = blob_bytes;
-            memcpy(blob.data(), grids.data(), off_pv);
-            HIPCHK(c, hipMemcpy(c->d_brdf, blob.data(), blob.size(), hipMemcpyHostToDevice));
-        }
-    }
+    rc = upload_brdf_tables(c, d, mats);
+    if (rc != PT_OK) return rc;
     HIPCHK(c, upload(&c->d_mats, mats.data(), mats.size()));
     HIPCHK(c, upload(&c->d_lights, d->lights, (size_t)d->n_lights));
     if (d->n_textures > 0) {
