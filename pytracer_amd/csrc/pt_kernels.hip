@@ -1109,10 +1109,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_splat(const RenderConst *__restric
     const int tw_l = SPLAT_PX + 2 * hx, th_l = 2 * hy + 1;
     const int lx0 = rc.tile.x0 + cx0 - hx, ly0 = py - hy;             // film coords of LDS tile origin
     const int plane = tw_l * th_l;
-    if (use_lds) {
+    static_assert(PT_BLOCK == 256, "one thread copies one entry of the 16x16 filter table");
+    __shared__ double s_table[256];          // the film's filter table (film.py:129-135): one LDS read per tap
+    s_table[threadIdx.x] = fm.table[threadIdx.x];
+    if (use_lds)
         for (int k = threadIdx.x; k < 4 * plane; k += PT_BLOCK) s_tile[k] = 0.;
-        __syncthreads();
-    }
+    __syncthreads();
     const int q = threadIdx.x % SPLAT_PX, sub = threadIdx.x / SPLAT_PX;
     const int px_t = cx0 + q;                                         // pixel column inside the tile
     const long P = st.stride;
@@ -1127,7 +1129,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_splat(const RenderConst *__restric
             for (int x = x0; x <= x1; x++) {
                 int ifx = (int)floor(fabs((x - dX) * 16 * xwInv));
                 ifx = min(ifx, 15);
-                const double wt = fm.table[ify * 16 + ifx];
+                const double wt = s_table[ify * 16 + ifx];
                 double *t = in_tile ? s_tile + (y - ly0) * tw_l + (x - lx0)
                                     : film + 4 * ((size_t)(y - fm.y_start) * fm.x_cnt + (x - fm.x_start));
                 const int cs = in_tile ? plane : 1;
@@ -1201,16 +1203,21 @@ __global__ __launch_bounds__(PT_BLOCK) void k_splat(const RenderConst *__restric
                 any = true;
             }
             if (!any) continue;
+            // the group's sum for every window pixel.  (Unrolling the 10 x 10 window of the 4-pixel filters so that the
+            // 5-bit fields come out with constant shifts doubled the kernel's time: 800 tap bodies.)
             for (int h = 0; h < H; h++) {
                 double *trow = s_tile + (wy0 + h - ly0) * tw_l + (wx0 - lx0);
+                int rowb[SPLAT_GROUP];
+#pragma unroll
+                for (int j = 0; j < SPLAT_GROUP; j++) rowb[j] = ((int)(cy[j] >> (5 * h)) & 31) * 16;
                 for (int w = 0; w < W; w++) {
                     double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
                     bool hitp = false;
 #pragma unroll
                     for (int j = 0; j < SPLAT_GROUP; j++) {
-                        const int ify = (int)(cy[j] >> (5 * h)) & 31, ifx = (int)(cx[j] >> (5 * w)) & 31;
-                        if ((ify | ifx) & 16) continue;
-                        const double wt = fm.table[ify * 16 + ifx];
+                        const int ifx = (int)(cx[j] >> (5 * w)) & 31;
+                        if ((rowb[j] | (ifx << 4)) & 256) continue;      // 31 in either field: not covered
+                        const double wt = s_table[rowb[j] + ifx];
                         a0 += wt * X[j]; a1 += wt * Y[j]; a2 += wt * Z[j]; a3 += wt;
                         hitp = true;
                     }
