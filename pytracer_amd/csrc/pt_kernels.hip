@@ -794,7 +794,7 @@ __device__ __forceinline__ void push_shadow(const ShadowQueue &sh, int region, b
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2
 #endif
-#define PT_SHADE_LDS_MATS 32      // 17 KB
+#define PT_SHADE_LDS_MATS 64      // 34 KB
 #define PT_SHADE_LDS_LIGHTS 16    // 4.5 KB (pt_scene_upload's limit)
 static_assert(sizeof(pt_material) % 8 == 0 && sizeof(pt_light) % 8 == 0, "copied to LDS in 8-byte words");
 // EXT (compile-time, so that plain scenes run the kernel unchanged): 0 = plain; 1 = the scene has textured lobes or
