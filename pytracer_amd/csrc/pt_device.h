@@ -376,15 +376,15 @@ __device__ __forceinline__ int grid_cell(double x, double bmin, double inv, int 
     const double c = floor((x - bmin) * inv);
     return c >= (double)(g - 1) ? g - 1 : (c > 0. ? (int)c : 0);     // NaN -> 0
 }
-// IrIsotropicBRDF.f, reflection/bdf/measured.py:51-66: the ball around m grows from .01 by 1.414 until it holds
-// more than two samples or its radius exceeds 1.5; the result is the mean of the samples in it, weighted
-// exp(-100 d^2).  query_ball_point (cKDTree, p = 2) = squared distance <= r*r.  Here the samples come from the grid,
-// every candidate is tested exactly, and the sums run in cell order.
 __device__ __forceinline__ double interval_dist(double x, double lo, double hi) {
     return x < lo ? lo - x : (x > hi ? x - hi : 0.);
 }
+// IrIsotropicBRDF.f, reflection/bdf/measured.py:51-66: the ball around m grows from .01 by 1.414 until it holds
+// more than two samples or its radius exceeds 1.5; the result is the mean of the samples in it, weighted
+// exp(-100 d^2).  query_ball_point (cKDTree, p = 2) = squared distance <= r*r.  Here the samples come from the grid,
+// every candidate is tested exactly, and the sums run in cell order (measured_f_as below has the algorithm).
 // One lane = one query, 64 different balls per wave, so the walk is divergent and VALU-bound (rocprofv3: 445 k VALU
-// against 27 k memory instructions per wave).  The samples found inside the ball are only LISTED during the scan
+// against 27 k memory instructions per wave).  The samples found inside a ball are LISTED during a scan
 // (`hits`: PT_MEAS_HITS ints per thread in LDS, thread-strided) and weighted afterwards, so exp() runs
 // max-over-lanes(samples in the ball) times per wave instead of once per scan step (some lane is inside its ball at
 // nearly every step).  Tried and rejected: one flat loop in which a lane either tests a candidate or steps to its
