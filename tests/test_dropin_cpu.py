@@ -62,6 +62,58 @@ print('OK')
     assert out.returncode == 0 and 'OK' in out.stdout, out.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference not present (GPU box)')
+def test_flatten_real_measured_material(golden_dir, tmp_path):
+    """The reference's own MeasuredMaterial, loaded from a .brdf file written here (the fixture generator's synthetic
+    format), goes through flatten's material walk; its IrIsotropicBRDF.f equals the oracle's lobe on the flattened
+    table; and a second MeasuredMaterial of the same file (the reference's cache stores its samples under a misspelt
+    name, material.py:434) is refused."""
+    import subprocess
+    code = r'''
+import sys, os, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import _shim
+import gen_fixtures as G
+import pytracer.geometry as geo
+from pytracer.material import MeasuredMaterial
+from pytracer.spectral.spectrum import SampledSpectrum
+from pytracer.reflection import IrIsotropicBRDF
+import pytracer_amd as pa
+from pytracer_amd import flatten as F, _abi as A
+import oracle_lib as O
+SampledSpectrum.init()
+path = G.write_synthetic_brdf(os.path.join(%r, 'dropin_test.brdf'), 120, 3)
+mat = MeasuredMaterial(path)
+kind, params = F.material_params(mat)
+assert kind == 'measured' and params['brdf_p'].shape == (120, 3)
+assert np.array_equal(params['brdf_p'], np.asarray(mat.theta_phi_tree.data))
+d = dict(np.load(%r))
+for k in [k for k in d if k.startswith('mat0_')]:
+    del d[k]
+d['mat0_kind'] = np.int32(6); d['mat0_brdf_p'] = params['brdf_p']; d['mat0_brdf_v'] = params['brdf_v']
+osc = O.OracleScene(pa.flat_scene_from_npz(d))
+b = IrIsotropicBRDF(mat.theta_phi_tree, mat.theta_phi_samples)
+rng = np.random.default_rng(1)
+for _ in range(40):
+    wo, wi = rng.normal(size=3), rng.normal(size=3)
+    wo /= np.linalg.norm(wo); wi /= np.linalg.norm(wi); wo[2] = abs(wo[2]); wi[2] = abs(wi[2])
+    want = np.array(b.f(geo.Vector(*wo), geo.Vector(*wi)))
+    got = osc.lobe_eval(0, 0, wo, wi, .3, .7)[:3]
+    assert np.allclose(got, want, rtol=1e-10, atol=0), (got, want)
+again = MeasuredMaterial(path)
+try:
+    F.material_params(again)
+    raise SystemExit('second MeasuredMaterial of one file was accepted')
+except ValueError:
+    pass
+print('OK')
+''' % (os.path.join(ROOT, 'tools', 'oracle'), ROOT, os.path.join(ROOT, 'tests'), str(tmp_path),
+       os.path.join(golden_dir, 'head_mesh_scene.npz'))
+    out = subprocess.run([sys.executable, '-W', 'ignore', '-c', code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+    assert out.returncode == 0 and 'OK' in out.stdout, out.stderr[-2000:]
+
+
 def test_shard_tile_partitions_exactly():
     smp = pa.sampler_desc(3, 67, 5, 50, 4, 2)
     for world in (1, 2, 3, 8):
