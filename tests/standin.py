@@ -28,9 +28,18 @@ def build_scene(d):
     mats = []
     for i in range(int(d['n_materials'])):
         pre = 'mat%d_' % i
-        if int(d[pre + 'kind']) == 0:
+        kind = int(d[pre + 'kind'])
+        if kind == 0:
             mats.append(_cls('MatteMaterial', Kd=ConstantTexture(d[pre + 'Kd']),
                              sigma=ConstantTexture(float(d[pre + 'sigma'])), bump_map=None))
+        elif kind == 2:
+            mats.append(_cls('PlasticMaterial', Kd=ConstantTexture(d[pre + 'Kd']), Ks=ConstantTexture(d[pre + 'Ks']),
+                             roughness=ConstantTexture(float(d[pre + 'roughness'])), bump_map=None))
+        elif kind == 6:      # a loaded MeasuredMaterial: samples with .p / .v and the tree over them (material.py:463-485)
+            smp = np.array([_cls('IrIsotropicBRDFSample', p=p_, v=v_) for p_, v_ in zip(d[pre + 'brdf_p'], d[pre + 'brdf_v'])],
+                           dtype=object)
+            mats.append(_cls('MeasuredMaterial', bump_map=None, regular_data=None, theta_phi_samples=smp,
+                             theta_phi_tree=_cls('cKDTree', data=d[pre + 'brdf_p'])))
         else:
             mats.append(_cls('UberMaterial', bump_map=None,
                              **{k: ConstantTexture(d[pre + k] if d[pre + k].ndim else float(d[pre + k]))

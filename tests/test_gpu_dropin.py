@@ -47,6 +47,26 @@ def test_renderer_fills_film_like_the_oracle(golden_dir, kind):
     np.testing.assert_allclose(film_arrays(camera.film), 2 * ref, rtol=1e-9, atol=1e-12)
 
 
+def test_renderer_with_measured_materials(golden_dir):
+    """The measmini scene (two MeasuredMaterials, Plastic, Matte; point + sphere lights) through the drop-in
+    renderer from reference-shaped objects: the film equals the oracle's."""
+    import oracle_lib as O
+    d = dict(np.load(os.path.join(golden_dir, 'measmini_direct_24x24x1.npz')))
+    scene = standin.build_scene(d)
+    camera = standin.build_camera(d)
+    sampler = standin.build_sampler(0, 24, 0, 24, 2, 2)
+    ren = GpuSamplerRenderer(sampler, camera, standin.build_integrator('path'), None, device=0, seed=5)
+    ren.render(scene)
+    got = film_arrays(camera.film)
+    flat = pa.flat_scene_from_npz(d)
+    assert len(flat.brdf_p) == 640
+    cam, film = pa.camera_film_from_npz(d)
+    ref, _ = O.OracleScene(flat).render(cam, film, pa.sampler_desc(0, 24, 0, 24, 2, 2, True, 5),
+                                        pa.integrator_desc(A.PT_INTEG_PATH, 5, False), pa.tile_desc(0, 24, 0, 24, 0, 4),
+                                        want_L=False)
+    assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max()        # measured lobes: tests/test_measmini.py on the bar
+
+
 def test_renderer_with_host_sampler_protocol(golden_dir):
     """sampler_mode='host': any object with generate(samples) drives the GPU path through the
     sample-table (parity) interface; here the captured reference stream is replayed."""
