@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 9
+#define PT_ABI_VERSION 10
 
 typedef enum {
     PT_OK = 0,

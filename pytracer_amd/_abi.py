@@ -1,7 +1,7 @@
 """ctypes mirror of include/pytracer_hip.h (struct layouts and enums only)."""
 import ctypes as C
 
-PT_ABI_VERSION = 9
+PT_ABI_VERSION = 10
 PT_MAX_LOBES = 5
 
 PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 0, -1, -2, -3, -4, -5

@@ -97,28 +97,40 @@ class Context(object):
         self._check(lib().pt_scene_upload(self._h, C.byref(d)))
         self._scene = flat
 
-    @staticmethod
-    def _stream(stream):
+    def _stream(self, stream):
         if stream is None:
             import torch
-            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)   # the CONTEXT's device
         return C.c_void_p(int(stream))
 
-    def intersect(self, rays, any_hit=False, stats=None, stream=None, want_bary=True):
+    def intersect(self, rays, any_hit=False, stats=None, stream=None, want_bary=True, static=False, out=None):
         """rays: torch float64 cuda tensor [8, n] (ox,oy,oz,dx,dy,dz,mint,maxt).
-        Returns (prim int32[n], t, b1, b2) — t/b1/b2 are None for any_hit."""
+        Returns (prim int32[n], t, b1, b2) — t/b1/b2 are None for any_hit.
+        static=True calls pt_intersect_static (the entry point that allocates nothing); `out` = a
+        (prim, t, b1, b2) tuple of preallocated tensors makes the whole call allocation-free."""
         import torch
         assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2 and rays.shape[0] == 8
-        rays = rays.contiguous()
+        assert rays.device.index == self.device, 'rays live on cuda:%s, the context on cuda:%d' % (rays.device.index, self.device)
+        if out is None:
+            rays = rays.contiguous()
+        else:
+            assert rays.is_contiguous()
         n = rays.shape[1]
-        prim = torch.empty(n, dtype=torch.int32, device=rays.device)
-        t = b1 = b2 = None
-        if not any_hit:
-            t = torch.empty(n, dtype=torch.float64, device=rays.device)
-            if want_bary:
-                b1 = torch.empty_like(t)
-                b2 = torch.empty_like(t)
-        self._check(lib().pt_intersect(self._h, rays.data_ptr(), n, int(bool(any_hit)), prim.data_ptr(),
+        if out is not None:
+            prim, t, b1, b2 = out
+            assert prim.dtype == torch.int32 and prim.is_cuda and prim.is_contiguous() and prim.numel() >= n
+            for x in (t, b1, b2):
+                assert x is None or (x.dtype == torch.float64 and x.is_cuda and x.is_contiguous() and x.numel() >= n)
+        else:
+            prim = torch.empty(n, dtype=torch.int32, device=rays.device)
+            t = b1 = b2 = None
+            if not any_hit:
+                t = torch.empty(n, dtype=torch.float64, device=rays.device)
+                if want_bary:
+                    b1 = torch.empty_like(t)
+                    b2 = torch.empty_like(t)
+        fn = lib().pt_intersect_static if static else lib().pt_intersect
+        self._check(fn(self._h, rays.data_ptr(), n, int(bool(any_hit)), prim.data_ptr(),
                                        t.data_ptr() if t is not None else None,
                                        b1.data_ptr() if b1 is not None else None,
                                        b2.data_ptr() if b2 is not None else None,

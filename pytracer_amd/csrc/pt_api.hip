@@ -9,6 +9,7 @@
 #include <math.h>
 #include <algorithm>
 #include <cmath>
+#include <new>
 #include <vector>
 
 #include "pt_kernels.h"
@@ -73,7 +74,26 @@ static int fail(pt_ctx *c, int code, const char *fmt, ...) {
 
 extern "C" int pt_version(void) { return PT_ABI_VERSION; }
 
+// Every entry point runs with the context's device current and puts the caller's device back on
+// every exit path: under torch a changed current device silently redirects the caller's next
+// allocations and current_stream() look-ups.
+struct DeviceGuard {
+    int prev;
+    hipError_t err;
+    explicit DeviceGuard(int dev) : prev(-1), err(hipSuccess) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+        else prev = -1;                      // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 static char g_create_err[512] = "null context";
+extern "C" int pt_ctx_destroy(pt_ctx *c);
 
 extern "C" const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
 
@@ -82,7 +102,7 @@ extern "C" const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err 
         hipError_t e_ = (call);                                                                        \
         if (e_ != hipSuccess) {                                                                        \
             snprintf(g_create_err, sizeof(g_create_err), "%s failed: %s", #call, hipGetErrorString(e_)); \
-            if (c) free(c);                                                                            \
+            if (c) (void)pt_ctx_destroy(c);      /* frees whatever was allocated so far */             \
             return PT_ERR_HIP;                                                                         \
         }                                                                                              \
     } while (0)
@@ -97,10 +117,15 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
         snprintf(g_create_err, sizeof(g_create_err), "device %d out of range (%d visible)", device, ndev);
         return PT_ERR_ARG;
     }
+    if (device >= PT_MAX_DEVICES) {
+        snprintf(g_create_err, sizeof(g_create_err), "device %d: at most %d devices per process", device, PT_MAX_DEVICES);
+        return PT_ERR_CAPACITY;
+    }
     c = (pt_ctx *)calloc(1, sizeof(pt_ctx));
     if (!c) return PT_ERR_ARG;
     c->device = device;
-    CREATE_CHK(hipSetDevice(device));
+    DeviceGuard dg(device);
+    CREATE_CHK(dg.err);
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -176,7 +201,7 @@ static void free_scene(pt_ctx *c) {
 
 extern "C" int pt_ctx_destroy(pt_ctx *c) {
     if (!c) return PT_OK;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     free_scene(c);
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_counts) (void)hipFree(c->d_counts);
@@ -373,7 +398,7 @@ static int upload_brdf_tables(pt_ctx *c, const pt_scene_desc *d, std::vector<pt_
     return PT_OK;
 }
 
-extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
+static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     if (!c || !d) return PT_ERR_ARG;
     if (d->n_nodes < 0 || d->n_tris < 0 || d->n_materials < 0 || d->n_lights < 0) return fail(c, PT_ERR_ARG, "negative count");
     if ((d->n_nodes && (!d->node_bounds || !d->node_meta)) ||
@@ -386,7 +411,8 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
             ((d->textures[i].kind == PT_TEX_CHECKER3D) != (d->textures[i].mapping == PT_MAP_IDENTITY3D)))
             return fail(c, PT_ERR_ARG, "texture %d: kind / mapping", i);
     if (d->n_lights > 16) return fail(c, PT_ERR_CAPACITY, "at most 16 lights");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard dg(c->device);
+    HIPCHK(c, dg.err);
     int depth = 0;
     int rc = check_tree(c, d, &depth);
     if (rc != PT_OK) return rc;
@@ -409,17 +435,20 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
             spec |= m.lobes[k].type == PT_LOBE_SPEC_REFLECT;
         }
     }
-    int spv = 0;
+    // Nothing of the context is touched before every check has passed: a rejected scene leaves the previous
+    // one (its light_ns, its shadow-queue sizing) exactly as it was.
+    int spv = 0, ns_new[16] = {0};
     double le[3] = {0, 0, 0};
     for (int i = 0; i < d->n_lights; i++) {
         const pt_light &l = d->lights[i];
         if (l.kind < 0 || l.kind > PT_LIGHT_POINT) return fail(c, PT_ERR_ARG, "light %d: kind", i);
         if (l.ns < 1 || l.ns > 16) return fail(c, PT_ERR_CAPACITY, "light %d: ns must be in 1..16", i);
-        c->light_ns[i] = l.ns;
+        ns_new[i] = l.ns;
         spv += l.ns;
         if (l.kind == PT_LIGHT_DIFFUSE_SPHERE) for (int k = 0; k < 3; k++) le[k] += l.emit[k];
     }
-    free_scene(c);
+    free_scene(c);          // the commit point: from here on the old scene is gone (have_scene = false)
+    memcpy(c->light_ns, ns_new, sizeof(c->light_ns));
     // build the device records
     std::vector<GNode> nodes((size_t)d->n_nodes);
     for (int i = 0; i < d->n_nodes; i++) {
@@ -536,6 +565,19 @@ extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
     return PT_OK;
 }
 
+// No C++ exception crosses the C ABI (std::vector growth on a huge scene): PT_ERR_CAPACITY, scene invalidated.
+extern "C" int pt_scene_upload(pt_ctx *c, const pt_scene_desc *d) {
+    try {
+        return scene_upload_impl(c, d);
+    } catch (const std::bad_alloc &) {
+        if (c) { DeviceGuard dg(c->device); free_scene(c); }
+        return fail(c, PT_ERR_CAPACITY, "out of host memory preparing the scene for upload");
+    } catch (...) {
+        if (c) { DeviceGuard dg(c->device); free_scene(c); }
+        return fail(c, PT_ERR_ARG, "unexpected C++ exception in pt_scene_upload");
+    }
+}
+
 // Grid of a trace launch: one full residency round (CUs x resident workgroups of that kernel),
 // grid-stride inside.  A grid that is not a multiple of the residency leaves a partial second
 // round: 2048 blocks on a 1280-block residency cost 14-17 % (scripts/trace_micro.py).
@@ -569,11 +611,11 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
                            n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
 }
 
-static int read_counters(pt_ctx *c, hipStream_t stream, pt_stats *stats) {
+// Sums the census shards at `src` (device) into stats.  Host side on the stack: no allocation of any kind.
+static int read_counters_from(pt_ctx *c, const unsigned long long *src, hipStream_t stream, pt_stats *stats) {
     static_assert(CNT_COUNT <= 16, "counter block");
-    std::vector<unsigned long long> sh((size_t)PT_CNT_SHARDS * CNT_COUNT);
-    HIPCHK(c, hipMemcpyAsync(sh.data(), c->d_counters, sh.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                             stream));
+    unsigned long long sh[PT_CNT_SHARDS * CNT_COUNT];
+    HIPCHK(c, hipMemcpyAsync(sh, src, sizeof(sh), hipMemcpyDeviceToHost, stream));
     HIPCHK(c, hipStreamSynchronize(stream));
     unsigned long long h[CNT_COUNT] = {0};
     for (int k = 0; k < PT_CNT_SHARDS; k++)
@@ -588,8 +630,13 @@ static int read_counters(pt_ctx *c, hipStream_t stream, pt_stats *stats) {
     stats->guard_inf += h[CNT_GUARD_INF];
     stats->node_visits_any += h[CNT_NODE_VISITS_ANY];
     stats->tri_tests_any += h[CNT_TRI_TESTS_ANY];
-    if (c->profiling) collect_timing(c, stats);
     return PT_OK;
+}
+
+static int read_counters(pt_ctx *c, hipStream_t stream, pt_stats *stats) {
+    int rc = read_counters_from(c, c->d_counters, stream, stats);
+    if (rc == PT_OK && c->profiling) collect_timing(c, stats);
+    return rc;
 }
 
 extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hit, int32_t *prim, double *t,
@@ -600,7 +647,8 @@ extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hi
     if (n == 0) return PT_OK;
     if (!rays || !prim) return fail(c, PT_ERR_ARG, "null rays/prim");
     hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard dg(c->device);
+    HIPCHK(c, dg.err);
     unsigned long long *cnt = nullptr;
     if (stats) {
         HIPCHK(c, hipMemsetAsync(c->d_counters, 0, PT_CNT_SHARDS * CNT_COUNT * sizeof(unsigned long long), stream));
@@ -720,7 +768,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     const long total = (long)(tile->x1 - tile->x0) * (tile->y1 - tile->y0) * (tile->s1 - tile->s0);
     if (total == 0) return PT_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard dg(c->device);
+    HIPCHK(c, dg.err);
 
     // paths in flight per wavefront pass.  288 GB of HBM makes a whole 1024^2 x 64 spp render
     // (67 M paths, ~430 B of state each ≈ 29 GB) one batch, which amortises the latency-bound
@@ -834,7 +883,8 @@ extern "C" int pt_film_resolve(pt_ctx *c, const double *film_accum, int32_t x_cn
                                void *stream_) {
     if (!c) return PT_ERR_ARG;
     if (!film_accum || !rgb || x_cnt < 0 || y_cnt < 0) return fail(c, PT_ERR_ARG, "film_resolve arguments");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard dg(c->device);
+    HIPCHK(c, dg.err);
     HIPCHK(c, pt_launch_film_resolve((hipStream_t)stream_, film_accum, (long)x_cnt * y_cnt, rgb));
     return PT_OK;
 }
@@ -844,7 +894,8 @@ extern "C" int pt_film_to_u8(pt_ctx *c, const double *rgb, int32_t x_cnt, int32_
     if (x_cnt < 0 || y_cnt < 0) return fail(c, PT_ERR_ARG, "film_to_u8 arguments");
     if ((long)x_cnt * y_cnt == 0) return PT_OK;      // np.max of an empty channel raises in the reference; nothing to write
     if (!rgb || !out) return fail(c, PT_ERR_ARG, "film_to_u8 arguments");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard dg(c->device);
+    HIPCHK(c, dg.err);
     HIPCHK(c, pt_launch_film_to_u8((hipStream_t)stream_, rgb, (long)x_cnt * y_cnt,
                                    c->d_counters + PT_CNT_SHARDS * CNT_COUNT, out));
     return PT_OK;

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <utility>
 #include <vector>
 
@@ -122,9 +123,9 @@ int64_t partition_bucket(std::vector<BuildPrim> &d, int64_t start, int64_t end, 
 
 extern "C" const char *pt_build_last_error(void) { return g_build_err; }
 
-extern "C" int pt_bvh_build(const double *prim_bounds, int64_t n, int32_t max_prim_per_node, int32_t method,
-                            double *node_bounds, int32_t *node_meta, int32_t *prim_order, int64_t *n_nodes,
-                            int32_t *max_depth) {
+static int bvh_build_impl(const double *prim_bounds, int64_t n, int32_t max_prim_per_node, int32_t method,
+                          double *node_bounds, int32_t *node_meta, int32_t *prim_order, int64_t *n_nodes,
+                          int32_t *max_depth) {
     g_build_err[0] = 0;
     if (n < 0 || n > 0x3FFFFFFF) return build_fail(PT_ERR_ARG, "primitive count %lld out of range", (long long)n);
     if (!n_nodes) return build_fail(PT_ERR_ARG, "null n_nodes");
@@ -241,4 +242,18 @@ extern "C" int pt_bvh_build(const double *prim_bounds, int64_t n, int32_t max_pr
     *n_nodes = count;
     if (max_depth) *max_depth = deepest;
     return PT_OK;
+}
+
+// No C++ exception crosses the C ABI: an allocation failure on a huge input is PT_ERR_CAPACITY.
+extern "C" int pt_bvh_build(const double *prim_bounds, int64_t n, int32_t max_prim_per_node, int32_t method,
+                            double *node_bounds, int32_t *node_meta, int32_t *prim_order, int64_t *n_nodes,
+                            int32_t *max_depth) {
+    try {
+        return bvh_build_impl(prim_bounds, n, max_prim_per_node, method, node_bounds, node_meta, prim_order, n_nodes,
+                              max_depth);
+    } catch (const std::bad_alloc &) {
+        return build_fail(PT_ERR_CAPACITY, "out of host memory building a tree over %lld primitives", (long long)n);
+    } catch (...) {
+        return build_fail(PT_ERR_ARG, "unexpected C++ exception in pt_bvh_build");
+    }
 }

@@ -8,9 +8,11 @@
 // for bit, so a scene built from it gets the reference's BVH and primitive ids (pt_bvh_build).
 // The vertex normals the reference also computes (:397-430) never reach the shading path (a mesh
 // with N but no S shades with its geometric frame, triangle.py:325) and are not produced.
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <unordered_map>
 #include <vector>
 
@@ -157,15 +159,18 @@ inline uint64_t edge_key(int a, int b) {   // SDEdge orders its ends (by id() th
 
 extern "C" const char *pt_subdiv_last_error(void) { return g_subdiv_err; }
 
-extern "C" int pt_loop_subdiv(const double *P, int64_t nv, const int32_t *vi, int64_t nf, int32_t n_levels,
-                              double *P_out, int64_t p_cap, int32_t *idx_out, int64_t idx_cap, int64_t *nv_out,
-                              int64_t *nf_out) {
+static int loop_subdiv_impl(const double *P, int64_t nv, const int32_t *vi, int64_t nf, int32_t n_levels,
+                            double *P_out, int64_t p_cap, int32_t *idx_out, int64_t idx_cap, int64_t *nv_out,
+                            int64_t *nf_out) {
     g_subdiv_err[0] = 0;
     if (!nv_out || !nf_out) return subdiv_fail(PT_ERR_ARG, "null count pointers");
     *nv_out = *nf_out = 0;
     if (nv <= 0 || nf <= 0 || !P || !vi) return subdiv_fail(PT_ERR_ARG, "empty mesh");
     if (n_levels < 0 || n_levels > 10) return subdiv_fail(PT_ERR_ARG, "n_levels %d", n_levels);
     if (nv > 0x3FFFFFFF || nf > 0x3FFFFFFF) return subdiv_fail(PT_ERR_CAPACITY, "mesh too large");
+    // nf * 4^levels faces come out: refuse what cannot be indexed with 32 bits before allocating for it
+    if (((long double)nf) * powl(4.0L, (long double)n_levels) > (long double)0x3FFFFFFF)
+        return subdiv_fail(PT_ERR_CAPACITY, "%lld faces x 4^%d levels exceed 2^30 triangles", (long long)nf, n_levels);
     for (int64_t k = 0; k < 3 * nf; k++)
         if (vi[k] < 0 || vi[k] >= nv) return subdiv_fail(PT_ERR_ARG, "vertex index %d out of range at %lld", vi[k], (long long)k);
 
@@ -313,4 +318,17 @@ extern "C" int pt_loop_subdiv(const double *P, int64_t nv, const int32_t *vi, in
     for (size_t i = 0; i < m.f.size(); i++)      // :433-439
         for (int j = 0; j < 3; j++) idx_out[3 * i + j] = m.f[i].v[j];
     return PT_OK;
+}
+
+// No C++ exception crosses the C ABI: an allocation failure (4^levels growth) is PT_ERR_CAPACITY.
+extern "C" int pt_loop_subdiv(const double *P, int64_t nv, const int32_t *vi, int64_t nf, int32_t n_levels,
+                              double *P_out, int64_t p_cap, int32_t *idx_out, int64_t idx_cap, int64_t *nv_out,
+                              int64_t *nf_out) {
+    try {
+        return loop_subdiv_impl(P, nv, vi, nf, n_levels, P_out, p_cap, idx_out, idx_cap, nv_out, nf_out);
+    } catch (const std::bad_alloc &) {
+        return subdiv_fail(PT_ERR_CAPACITY, "out of host memory subdividing %lld faces %d times", (long long)nf, n_levels);
+    } catch (...) {
+        return subdiv_fail(PT_ERR_ARG, "unexpected C++ exception in pt_loop_subdiv");
+    }
 }

@@ -57,8 +57,10 @@ def write_film_image(film_obj, rgb8, update='reference'):
                        int(film_obj.xPixel_start), int(film_obj.yPixel_start), update=update)
 
 
-def render_key(flat, cam, film, smp, integ, tile, sampler_mode='device'):
-    """Digest of everything that determines the accumulators of a tile: scene arrays, descriptors."""
+def render_key(flat, cam, film, smp, integ, tile, sampler_mode='device', table=None):
+    """Digest of everything that determines the accumulators of a tile: scene arrays (the measured BRDF
+    tables included: a measured lobe's packed record only names its sample range), descriptors, and for
+    sampler_mode='host' the host sampler's sample table."""
     h = hashlib.sha256()
     for a in (flat.node_bounds, flat.node_meta, flat.tri_verts, flat.tri_mat, flat.tri_flip):
         h.update(np.ascontiguousarray(a).tobytes())
@@ -67,6 +69,11 @@ def render_key(flat, cam, film, smp, integ, tile, sampler_mode='device'):
     h.update(bytes(flat._textures))
     if flat.tri_uv is not None:
         h.update(flat.tri_uv.tobytes())
+    for a in (getattr(flat, 'brdf_p', None), getattr(flat, 'brdf_v', None)):
+        if a is not None and len(a):
+            h.update(np.ascontiguousarray(a).tobytes())
+    if table is not None:
+        h.update(np.ascontiguousarray(table).tobytes())
     for d in (cam, film, smp, integ, tile):
         h.update(bytes(d))
     h.update(sampler_mode.encode())

@@ -164,17 +164,17 @@ class GpuSamplerRenderer(object):
             self._ctx = Context(dev.index)
         ctx = self._ctx
         ctx.upload(flat)
-        table = None
+        table = table_host = None
         if self.sampler_mode == 'host':
-            t = host_sample_table(self.sampler, self.surf_integrator, scene, flat.table_dims(integ.kind))
-            table = torch.from_numpy(t).to(dev)
+            table_host = host_sample_table(self.sampler, self.surf_integrator, scene, flat.table_dims(integ.kind))
+            table = torch.from_numpy(table_host).to(dev)
         acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device=dev)
         self.stats = A.pt_stats()
         ckpt, start = None, None
         self.resumed_from = None
         if self.checkpoint:
             path = self.checkpoint if world == 1 else '%s.rank%d' % (self.checkpoint, rank)
-            ckpt = IO.Checkpoint(path, IO.render_key(flat, cam, film, smp, integ, tile, self.sampler_mode))
+            ckpt = IO.Checkpoint(path, IO.render_key(flat, cam, film, smp, integ, tile, self.sampler_mode, table_host))
             found = ckpt.load(tuple(acc.shape))
             if found is not None:
                 acc.copy_(torch.from_numpy(found[0]))

@@ -122,3 +122,27 @@ def test_pieces_add_up_and_key_tells_renders_apart(golden_dir):
     assert k != IO.render_key(flat, cam, film, smp, pa.integrator_desc(A.PT_INTEG_DIRECT, 5, False), tile)
     assert k != IO.render_key(flat, cam, film, smp, integ, pa.tile_desc(44, 68, 44, 68, 0, 3))
     assert k != IO.render_key(flat, cam, film, smp, integ, tile, 'host')
+    assert k != IO.render_key(flat, cam, film, smp, integ, tile, 'host', np.zeros((4, 35)))
+    assert (IO.render_key(flat, cam, film, smp, integ, tile, 'host', np.zeros((4, 35))) !=
+            IO.render_key(flat, cam, film, smp, integ, tile, 'host', np.ones((4, 35))))
+
+
+def test_key_covers_measured_brdf_tables(golden_dir):
+    """Two measured-BRDF tables with the same sample count give the same packed lobe record (first, count):
+    the key must still tell them apart, or a checkpoint of one material would be resumed into the other."""
+    from pytracer_amd import workloads
+    flat = workloads.c5_head_measured(os.path.join(golden_dir, 'head_mesh_scene.npz'))
+    d = dict(np.load(os.path.join(golden_dir, 'head_mesh_scene.npz')))
+    cam, film = pa.camera_film_from_npz(d)
+    smp = pa.sampler_desc(44, 68, 44, 68, 2, 2, True, 9)
+    integ = pa.integrator_desc(A.PT_INTEG_PATH, 5, False)
+    tile = pa.tile_desc(44, 68, 44, 68, 0, 4)
+    k = IO.render_key(flat, cam, film, smp, integ, tile)
+    assert len(flat.brdf_v) > 0
+    keep = flat.brdf_v.copy()
+    flat.brdf_v[0, 0] += 1e-3
+    assert k != IO.render_key(flat, cam, film, smp, integ, tile)
+    flat.brdf_v[:] = keep
+    assert k == IO.render_key(flat, cam, film, smp, integ, tile)
+    flat.brdf_p[1, 2] += 1e-3
+    assert k != IO.render_key(flat, cam, film, smp, integ, tile)
