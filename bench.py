@@ -11,9 +11,16 @@ Lanczos(4,4,3) film.  One "step" = one full render: sample generation → camera
 closest/any hit → shading/light sampling → film splat (+ RCCL reduce of the film for N > 1)
 → film resolve.  Inputs (scene, descriptors) are resident in HBM before the timed region.
 
-Multi-GPU: replicated scene, every rank renders all pixels with its own 64-spp sample stream
-(seed = rank), i.e. per-GPU work is fixed ("weak" scaling: N GPUs give a 64·N spp image in the
-same time); the only collective is the reduce of the film accumulators to rank 0.
+Multi-GPU (default, "strong" scaling — the metric's job is the FIXED 1024^2 x 64 spp render at 1/2/4/8 GPUs):
+replicated scene, same seed on every rank, rank r renders `renderer.shard_tile(sampler, r, N, 'samples')` = sample
+indices [64 r / N, 64 (r+1) / N) of every pixel (the reference's own decomposition hook is
+Sampler.compute_subwindow, sampler/sampler/__init__.py:87-111, unused there: renderer.py:97-109); the only
+collective is one reduce(sum) of the f64 film accumulators to rank 0.  Sample streams are functions of (pixel,
+sample index, seed), so the N-rank film equals the 1-rank film up to the order of the additions: rank 0 renders the
+1-rank image once more OUTSIDE the timed region and prints both checksums (`image_checksum`, `image_checksum_n1`).
+`--weak` keeps the round-1 behaviour (every rank its own 64-spp stream, seed = rank: a 64 N spp image).
+`--shard-of 1,2,4,8` (one GPU): times shard 0 of K for every K listed and prints `shard_proxy` =
+t(64 spp) / (K t(64/K spp)), the efficiency an N = K run can reach before the film reduce.
 
 Prints ONE JSON line on rank 0 (see the driver contract); extra keys: `roofline` for the
 dominant kernel and `cpu_baseline` (the CPU oracle timed on this box's host, rank 0, N=1 only).
@@ -46,6 +53,9 @@ def parse():
     ap.add_argument('--spp', type=int, default=8, help='strata per axis (spp = spp^2; c5: spp x spp/2)')
     ap.add_argument('--integrator', choices=['path', 'direct'], default='path')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--weak', action='store_true', help='N > 1: per-rank sample streams (seed = rank), 64 spp per rank')
+    ap.add_argument('--shard-of', default='', help='one GPU: comma list of K; time shard 0 of K for each (scaling proxy)')
+    ap.add_argument('--shard-mode', choices=['samples', 'rows'], default='samples')
     ap.add_argument('--workload', choices=['head', 'c2', 'c4', 'c5'], default='head',
                     help='head = BASELINE.json configs[2] (the metric; default).  Secondary, for DESIGN.md only: '
                          'c2 = configs[1] head_loop 512^2 x 16 spp Direct; c4 = configs[3] 10^6-triangle soup '
@@ -173,8 +183,11 @@ def main():
     ctx.set_profiling(True)
     integ = pa.integrator_desc(kind, 5, pretest=False)
     ys = xs if ys is None else ys
-    smp = pa.sampler_desc(0, xres, 0, yres, xs, ys, True, seed=rank)
-    tile = pa.tile_desc(0, xres, 0, yres, 0, xs * ys)
+    from pytracer_amd.renderer import shard_tile
+    strong = world > 1 and not args.weak
+    smp = pa.sampler_desc(0, xres, 0, yres, xs, ys, True, seed=rank if (world > 1 and args.weak) else 0)
+    full_tile = pa.tile_desc(0, xres, 0, yres, 0, xs * ys)
+    tile = shard_tile(smp, rank, world, args.shard_mode) if strong else full_tile
     acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device=dev)
 
     def barrier():
@@ -182,9 +195,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(stats):
+    def step(stats, t=None):
         acc.zero_()
-        ctx.render(cam, film, smp, integ, tile, acc, stats=stats)
+        ctx.render(cam, film, smp, integ, tile if t is None else t, acc, stats=stats)
         if dist is not None:
             dist.reduce(acc, dst=0)             # RCCL sum of film accumulators over xGMI
         return ctx.film_resolve(acc)
@@ -208,6 +221,45 @@ def main():
     else:
         rays_total, samples_total = float(st.rays_closest + st.rays_any), float(st.camera_samples)
 
+    # N > 1, strong scaling: the same job on one rank, outside the timed region, for the checksum comparison
+    checksum_n1 = None
+    if strong and rank == 0:
+        acc1 = torch.zeros_like(acc)
+        ctx.render(cam, film, smp, integ, full_tile, acc1, stats=A.pt_stats())
+        checksum_n1 = float(ctx.film_resolve(acc1).sum().item())
+        del acc1
+    # one GPU: shard 0 of K for every K asked for (what an N = K run can reach before the film reduce)
+    proxy = None
+    if world == 1 and args.shard_of:
+        proxy = {}
+        t_full = None
+        for K in sorted(set([1] + [int(k) for k in args.shard_of.split(',') if k.strip()])):
+            tk = shard_tile(smp, 0, K, args.shard_mode)
+            step(A.pt_stats(), tk)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step(A.pt_stats(), tk)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / args.steps * 1e3
+            if K == 1:
+                t_full = ms
+            proxy[str(K)] = {'ms_per_step': ms, 'spp_per_shard': tk.s1 - tk.s0, 'rows_per_shard': tk.y1 - tk.y0,
+                             'predicted_efficiency': t_full / (K * ms)}
+        # the reduce itself cannot be timed on one GPU: its on-device half (acc += other, 32 MiB f64) can
+        other = torch.ones_like(acc)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            acc.add_(other)
+        torch.cuda.synchronize()
+        proxy['film_add_ms'] = (time.perf_counter() - t1) / 20 * 1e3
+        proxy['film_bytes'] = acc.numel() * 8
+        proxy['note'] = ('predicted_efficiency = t(K=1) / (K t(shard 0 of K)), same process, film resolve included; the '
+                         'xGMI transfer of the reduce is not measurable on one GPU: film_bytes over a ring at ~153 GB/s '
+                         'per link is ~0.2-0.4 ms (SURVEY.md section 5)')
+        del other
+
     if rank == 0:
         # dominant kernel: whichever of the two traversal kernels took more time
         n_any, n_clo = st.rays_any, st.rays_closest
@@ -222,15 +274,31 @@ def main():
         name = max(cand, key=lambda k: cand[k][0])
         ms, launches, abytes, nr, nv, nt = cand[name]
         achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic = None
+        # `traffic` is NOT measured by this run: PMC counters need rocprofv3 passes of their own.  It is the recorded
+        # figure of profiles/pmc_summary.json (2 x FETCH_SIZE + WRITE_SIZE per launch of this kernel on the headline
+        # workload), valid for the commit named there; other workloads / sizes get null.
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-        if os.path.exists(pmc):
+        headline = args.workload == 'head' and res == 1024 and xs * ys == 64 and kind == A.PT_INTEG_PATH and world == 1
+        if os.path.exists(pmc) and headline:
             try:
-                traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
+                pj = json.load(open(pmc))
+                traffic = pj.get(name, {}).get('hbm_bytes_per_launch')
+                meta = pj.get('_meta', {})
+                traffic_source = {'file': 'profiles/pmc_summary.json', 'csv': pj.get(name, {}).get('source'),
+                                  'commit': meta.get('commit'), 'recorded': meta.get('recorded'),
+                                  'note': 'recorded rocprofv3 --pmc passes, not measured in this run'}
             except Exception:
                 traffic = None
+        avg_ms = ms / max(launches, 1)
         roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': name,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
+                # what the HBM actually carries: the tree is cache-resident, so this is far below `frac`, which prices
+                # every node / triangle byte as if streamed.  The real limiter is named here.
+                'hbm_traffic_frac': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
+                'limiter': 'vector-memory (L1/TA) line rate and dependent-fetch latency of per-lane node loads; '
+                           'HBM carries the ray/hit streams only (DESIGN.md section 5-6)',
+                'kernel': name,
                 'kernel_note': 'closest-hit launches run k_trace_meta<false> (child words in LDS) on trees of up to ~7900 '
                                'nodes, k_trace<STACK,false> otherwise; profiles/ lists the symbol under full_name',
                 'launches': int(launches), 'avg_launch_ms': ms / max(launches, 1),
@@ -242,15 +310,24 @@ def main():
             'metric': 'Mrays/s', 'value': rays_total / dt / 1e6, 'unit': 'Mrays/s',
             'samples_per_s': samples_total / dt,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': wname % (xres, yres, xs * ys, 'PathIntegrator' if kind else 'DirectLightingIntegrator'),
                        'triangles': flat.n_tris, 'bvh_nodes': flat.n_nodes,
                        'rays_per_sample': rays_total / max(samples_total, 1),
-                       'parallelism': 'replicated scene, per-rank sample streams, RCCL film reduce'
-                       if world > 1 else 'single GPU',
+                       'parallelism': ('single GPU' if world == 1 else
+                                       'replicated scene, per-rank sample streams (seed = rank), RCCL film reduce' if args.weak
+                                       else 'replicated scene, fixed job sharded by %s (shard_tile), one RCCL film reduce'
+                                       % ('sample index' if args.shard_mode == 'samples' else 'row bands')),
                        'image_checksum': float(rgb.sum().item())},
             'roofline': roof,
         }
+        if checksum_n1 is not None:
+            out['config']['image_checksum_n1'] = checksum_n1
+            out['config']['checksum_rel_diff'] = abs(out['config']['image_checksum'] - checksum_n1) / max(abs(checksum_n1), 1e-300)
+            assert out['config']['checksum_rel_diff'] <= 1e-9, 'the sharded film differs from the 1-rank film: %r' % out['config']
+        if proxy is not None:
+            out['shard_proxy'] = proxy
         if world == 1 and not args.no_cpu_baseline and args.workload == 'head':
             out['cpu_baseline'] = cpu_baseline(flat, cam, film, integ, res, xs)
         print(json.dumps(out))

@@ -1,0 +1,85 @@
+"""BASELINE.json configs[2] at its real size on the GPU — head mesh 1024x1024, 8x8 = 64 spp, PathIntegrator depth 5 —
+(a) as the multi-GPU job: the K shards `renderer.shard_tile` hands to K ranks, rendered one after another on one
+GPU, add up to the one-rank film (what bench.py --gpus K reduces over RCCL; the reference's hook is
+Sampler.compute_subwindow, sampler/sampler/__init__.py:87-111), for both shard modes;
+(b) one window of the full-size render against the oracle, per sample (1e-9) and on the film."""
+import os
+
+import numpy as np
+import pytest
+
+import pytracer_amd as pa
+from pytracer_amd import _abi as A
+from pytracer_amd import host
+from pytracer_amd.renderer import shard_tile
+
+pytestmark = pytest.mark.gpu
+
+RES, XS = 1024, 8
+
+
+@pytest.fixture(scope='module')
+def c3(golden_dir):
+    import torch
+    from pytracer_amd._lib import Context
+    assert torch.cuda.is_available()
+    d = dict(np.load(os.path.join(golden_dir, 'head_mesh_scene.npz')))
+    flat = pa.flat_scene_from_npz(d)
+    ctx = Context(0)
+    ctx.upload(flat)
+    cam, film = host.head_mesh_camera_film(RES, RES)
+    smp = pa.sampler_desc(0, RES, 0, RES, XS, XS, True, 0)
+    integ = pa.integrator_desc(A.PT_INTEG_PATH, 5, False)
+    yield torch, ctx, flat, cam, film, smp, integ
+    ctx.close()
+
+
+def _render(torch, ctx, cam, film, smp, integ, tiles):
+    acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
+    st = A.pt_stats()
+    for t in tiles:
+        ctx.render(cam, film, smp, integ, t, acc, stats=st)
+    torch.cuda.synchronize()
+    return acc, st.as_dict()
+
+
+def test_c3_shards_add_up_to_the_one_rank_film(c3):
+    torch, ctx, flat, cam, film, smp, integ = c3
+    whole, s1 = _render(torch, ctx, cam, film, smp, integ, [pa.tile_desc(0, RES, 0, RES, 0, XS * XS)])
+    assert s1['camera_samples'] == RES * RES * XS * XS
+    scale = float(whole.abs().max())
+    for K, mode in ((2, 'samples'), (8, 'samples'), (4, 'rows')):
+        tiles = [shard_tile(smp, r, K, mode) for r in range(K)]
+        if mode == 'samples':
+            assert [(t.s0, t.s1) for t in tiles] == [(64 * r // K, 64 * (r + 1) // K) for r in range(K)]
+        parts, sk = _render(torch, ctx, cam, film, smp, integ, tiles)
+        # same samples, same arithmetic; only the order of the f64 atomic additions differs
+        assert float((parts - whole).abs().max()) <= 1e-12 * scale, (K, mode)
+        for k in ('camera_samples', 'rays_closest', 'rays_any', 'node_visits', 'tri_tests', 'guard_nan', 'guard_neg',
+                  'guard_inf'):
+            assert sk[k] == s1[k], (K, mode, k)
+        del parts
+
+
+def test_c3_full_size_window_against_the_oracle(c3):
+    import oracle_lib as O
+    torch, ctx, flat, cam, film, smp, integ = c3
+    osc = O.OracleScene(flat)
+    for (x0, y0, w) in ((560, 300, 24), (180, 700, 24)):          # on the head / head silhouette + backdrop
+        wt = pa.tile_desc(x0, x0 + w, y0, y0 + w, 0, XS * XS)
+        n = w * w * XS * XS
+        acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
+        L = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
+        sg, so = A.pt_stats(), A.pt_stats()
+        ctx.render(cam, film, smp, integ, wt, acc, sample_L=L, stats=sg)
+        torch.cuda.synchronize()
+        oacc, oL = osc.render(cam, film, smp, integ, wt, stats=so)
+        gL = L.cpu().numpy()
+        assert np.isfinite(gL).all()
+        scale = np.maximum(np.abs(oL).max(axis=-1, keepdims=True), 1e-12)        # per sample, as in the other parity tests
+        assert (np.abs(gL - oL) / scale).max() <= 1e-9
+        g = acc.cpu().numpy()
+        assert np.abs(g - oacc).max() <= 1e-9 * np.abs(oacc).max()
+        for k in ('camera_samples', 'rays_closest', 'rays_any'):
+            assert sg.as_dict()[k] == so.as_dict()[k], k
+        assert sg.camera_samples == n

@@ -21,7 +21,7 @@ def test_bench_json_contract():
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
     assert d['metric'] == 'Mrays/s' and d['unit'] == 'Mrays/s' and d['n_gpus'] == 1 and d['steps'] == 2
-    assert d['dtype'] == 'f64' and d['vs_baseline'] is None and d['higher_is_better'] is True and d['scaling'] == 'weak'
+    assert d['dtype'] == 'f64' and d['vs_baseline'] is None and d['higher_is_better'] is True and d['scaling'] == 'strong'
     assert 'workload' in d['config'] and 'model' not in d['config']
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
