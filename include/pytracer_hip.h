@@ -233,6 +233,26 @@ int pt_intersect(pt_ctx *ctx, const double *rays, int64_t n, int any_hit,
                  int32_t *prim, double *t, double *b1, double *b2,
                  pt_stats *stats, void *stream);
 
+/* No counterpart in the reference.  pt_intersect for callers that cannot allocate device memory: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same results
+ * and the same census as pt_intersect (it launches the same kernels), but the call allocates and frees
+ * nothing: the census counters of the launch — the one scratch buffer the trace kernels use beyond their
+ * inputs and outputs — live in a file-scope `static __device__` array of the library (20 KB per GPU the
+ * library has a context on, held until the process ends) instead of the context's hipMalloc'ed block, and no
+ * profiling events are created (pt_set_profiling is ignored).
+ *   n      at most PT_INTERSECT_STATIC_MAX_RAYS per call; more → PT_ERR_CAPACITY, nothing launched
+ *   stats  NULL: the call enqueues a memset of the scratch and the trace kernel on `stream` and returns
+ *          without synchronising (capturable).  Non-NULL: it then copies the 20 KB of counters to the host
+ *          stack and synchronises `stream`, like pt_intersect.
+ * All calls on one GPU share that GPU's array, which keeps the last call's sums (every call clears it first):
+ * two pt_intersect_static calls that overlap on one GPU — different streams or different contexts of the
+ * same device — race on the census (the hit records stay correct).  Serialise them, or pass stats == NULL
+ * on all but one. */
+#define PT_INTERSECT_STATIC_MAX_RAYS 0x40000000LL
+int pt_intersect_static(pt_ctx *ctx, const double *rays, int64_t n, int any_hit,
+                        int32_t *prim, double *t, double *b1, double *b2,
+                        pt_stats *stats, void *stream);
+
 /* replaces: the body of SamplerRendererTask.__call__ (renderer/renderer.py:132-198):
  * sample generation → camera ray → SamplerRenderer.li → guards → ImageFilm.add_sample.
  *   sample_table  device f64 [n_window_samples][dims] or NULL.  Non-NULL = parity mode:

@@ -2,6 +2,7 @@
 import ctypes as C
 
 PT_ABI_VERSION = 10
+PT_INTERSECT_STATIC_MAX_RAYS = 0x40000000
 PT_MAX_LOBES = 5
 
 PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 0, -1, -2, -3, -4, -5

@@ -13,7 +13,7 @@ if os.environ.get('PYTRACER_HIP_LIB'):        # kernel A/B experiments only (scr
     LIB_PATH = os.path.abspath(os.environ['PYTRACER_HIP_LIB'])
 
 EXPORTS = ('pt_version', 'pt_ctx_create', 'pt_ctx_destroy', 'pt_last_error', 'pt_scene_upload', 'pt_intersect',
-           'pt_render', 'pt_film_resolve', 'pt_film_to_u8', 'pt_set_profiling', 'pt_bvh_build', 'pt_build_last_error',
+           'pt_intersect_static', 'pt_render', 'pt_film_resolve', 'pt_film_to_u8', 'pt_set_profiling', 'pt_bvh_build', 'pt_build_last_error',
            'pt_loop_subdiv', 'pt_subdiv_last_error')
 
 _lib = None
@@ -45,6 +45,7 @@ def lib():
         L.pt_scene_upload.argtypes = [C.c_void_p, C.POINTER(A.pt_scene_desc)]
         L.pt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.POINTER(A.pt_stats), C.c_void_p]
+        L.pt_intersect_static.argtypes = L.pt_intersect.argtypes
         L.pt_render.argtypes = [C.c_void_p, C.POINTER(A.pt_camera), C.POINTER(A.pt_film_desc),
                                 C.POINTER(A.pt_sampler_desc), C.POINTER(A.pt_integrator_desc), C.POINTER(A.pt_tile),
                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(A.pt_stats), C.c_void_p]

@@ -92,6 +92,15 @@ struct DeviceGuard {
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
+// Scratch of pt_intersect_static (include/pytracer_hip.h): the sharded census counters of one trace launch
+// ([PT_CNT_SHARDS][CNT_COUNT] u64 = 20 KB), in a file-scope device array instead of memory from hipMalloc.
+// Every GPU the library runs on holds its own copy at its own address until the process ends.  In host code
+// the NAME of the array is only a stand-in for hipGetSymbolAddress: the address a kernel may use is looked
+// up once per device in pt_ctx_create, with that device current, and kept in g_static_scratch[device].
+#define PT_STATIC_SCRATCH_WORDS (PT_CNT_SHARDS * CNT_COUNT)
+static __device__ __align__(256) unsigned long long scratch[PT_STATIC_SCRATCH_WORDS];
+static unsigned long long *g_static_scratch[PT_MAX_DEVICES];
+
 static char g_create_err[512] = "null context";
 extern "C" int pt_ctx_destroy(pt_ctx *c);
 
@@ -126,6 +135,11 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     c->device = device;
     DeviceGuard dg(device);
     CREATE_CHK(dg.err);
+    if (!g_static_scratch[device]) {     // once per device, with that device current (see `scratch` above)
+        unsigned long long *p = nullptr;
+        CREATE_CHK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        g_static_scratch[device] = p;
+    }
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -662,6 +676,33 @@ extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hi
                                cnt));
     }
     if (stats) return read_counters(c, stream, stats);
+    return PT_OK;
+}
+
+// pt_intersect for callers that cannot allocate (include/pytracer_hip.h): the census counters live in the
+// file-scope device array `scratch` (through its per-device address, never its name), no event is created,
+// nothing is allocated or freed.  With stats == NULL the call is two asynchronous operations on `stream`
+// (a 20 KB memset of the scratch and the trace launch) and returns without synchronising.
+extern "C" int pt_intersect_static(pt_ctx *c, const double *rays, int64_t n, int any_hit, int32_t *prim, double *t,
+                                   double *b1, double *b2, pt_stats *stats, void *stream_) {
+    if (!c) return PT_ERR_ARG;
+    if (!c->have_scene) return fail(c, PT_ERR_NO_SCENE, "pt_intersect_static before pt_scene_upload");
+    if (n < 0) return fail(c, PT_ERR_ARG, "ray count %lld is negative", (long long)n);
+    if (n > PT_INTERSECT_STATIC_MAX_RAYS)
+        return fail(c, PT_ERR_CAPACITY, "pt_intersect_static: %lld rays exceed the maximum of %lld per call",
+                    (long long)n, (long long)PT_INTERSECT_STATIC_MAX_RAYS);
+    if (n == 0) return PT_OK;
+    if (!rays || !prim) return fail(c, PT_ERR_ARG, "null rays/prim");
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard dg(c->device);
+    HIPCHK(c, dg.err);
+    unsigned long long *cnt = g_static_scratch[c->device];      // looked up in pt_ctx_create on this device
+    if (!cnt) return fail(c, PT_ERR_HIP, "static scratch of device %d has no address", c->device);
+    // the array keeps the previous call's sums: the census starts at zero
+    HIPCHK(c, hipMemsetAsync(cnt, 0, PT_STATIC_SCRATCH_WORDS * sizeof(unsigned long long), stream));
+    const ShadowResolve rs = {nullptr, 0, nullptr, nullptr, 0};
+    HIPCHK(c, launch_trace(c, any_hit != 0, (long)n, stream, rays, (long)n, nullptr, 0, (int)n, prim, t, b1, b2, rs, cnt));
+    if (stats) return read_counters_from(c, cnt, stream, stats);
     return PT_OK;
 }
 
