@@ -21,6 +21,9 @@ struct pt_ctx {
     bool have_scene;
     DScene sc;
     void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf;
+    void *d_pairs;           // GPair records of the interior nodes (k_trace_pair)
+    int n_pairs;
+    int use_pair;            // PT_TRACE_PAIR: 0 never, 1 always, unset (-1) = by tree size (launch_trace)
     size_t brdf_bytes;
     int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
     int meta_stack;          // todo levels of k_trace_meta's LDS stacks (0: the tree's child words do not fit in LDS)
@@ -43,6 +46,11 @@ struct pt_ctx {
     int *hit_idx;            // [cap] hit list of the current closest-hit trace (HitList::idx)
     int *d_counts;           // [4][PT_SEG]: region fill counters of q0, q1, the shadow queue and the hit list
     int trace_occ[2];        // resident blocks/CU of the closest / any trace kernels (0 = not queried)
+    int pair_occ[2];         // the same for k_trace_pair
+    int pair_levels;         // todo levels the tree needs; the first pair_lds_levels of them live in LDS (PT_PAIR_LDS_LEVELS)
+    int pair_lds_levels;
+    long pair_max_blocks;    // grid limit of k_trace_pair = what d_spill was sized for (a multiple of PT_SEG_BLOCKS)
+    void *d_spill;           // global part of k_trace_pair's todo stacks
     RenderConst *d_rc;
     unsigned long long *d_counters;
     int n_cu;
@@ -148,6 +156,8 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     if (const char *e = getenv("PT_TRACE_TOP")) c->use_top = atoi(e);
     c->use_meta = 1;
     if (const char *e = getenv("PT_TRACE_META")) c->use_meta = atoi(e);
+    c->use_pair = -1;
+    if (const char *e = getenv("PT_TRACE_PAIR")) c->use_pair = atoi(e);
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
     // + 4 words behind the census shards: the channel maxima of pt_film_to_u8
     CREATE_CHK(hipMalloc((void **)&c->d_counters, (PT_CNT_SHARDS * CNT_COUNT + 4) * sizeof(unsigned long long)));
@@ -205,7 +215,7 @@ static void collect_timing(pt_ctx *c, pt_stats *stats) {
 
 static void free_scene(pt_ctx *c) {
     void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top,
-                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf};
+                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -483,7 +493,51 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
             g.e1[k] = v[3 + k] - v[k];   // e1 = p2 - p1, triangle.py:183
             g.e2[k] = v[6 + k] - v[k];   // e2 = p3 - p1, triangle.py:184
         }
-        g._pad = 0;
+        g.leaf_nprim = 0;
+        g.leaf_node = 0;
+    }
+    // children-pair records (k_trace_pair): interior nodes numbered in depth-first (= index) order, root = pair 0
+    {
+        std::vector<int32_t> pair_of((size_t)d->n_nodes, -1);
+        int32_t n_pairs = 0;
+        for (int i = 0; i < d->n_nodes; i++)
+            if ((nodes[i].nprim_axis & 0xFFFF) == 0) pair_of[(size_t)i] = n_pairs++;
+            else {
+                GTri &t0 = tris[(size_t)nodes[i].offset];       // leaf ranges were validated by check_tree
+                t0.leaf_nprim = nodes[i].nprim_axis & 0xFFFF;
+                t0.leaf_node = i;
+            }
+        std::vector<GPair> pairs((size_t)n_pairs);
+        for (int i = 0; i < d->n_nodes; i++) {
+            if (pair_of[(size_t)i] < 0) continue;
+            GPair &p = pairs[(size_t)pair_of[(size_t)i]];
+            memset(&p, 0, sizeof(p));
+            const int ch[2] = {i + 1, nodes[i].offset};
+            for (int k = 0; k < 2; k++) {
+                const GNode &g = nodes[(size_t)ch[k]];
+                double *b = k ? p.b1 : p.b0;
+                memcpy(b, g.bmin, 3 * sizeof(double));
+                memcpy(b + 3, g.bmax, 3 * sizeof(double));
+                const int32_t ref = (g.nprim_axis & 0xFFFF) ? ~g.offset : pair_of[(size_t)ch[k]];
+                (k ? p.ref1 : p.ref0) = ref;
+                (k ? p.node1 : p.node0) = ch[k];
+            }
+            p.axis = nodes[i].nprim_axis >> 16;
+            p.self = i;
+        }
+        c->n_pairs = n_pairs;
+        if (n_pairs > 0) {
+            HIPCHK(c, upload(&c->d_pairs, pairs.data(), pairs.size()));
+            // todo stacks: <= one entry per level of the tree (+ margin); the first L levels in LDS, all of them again
+            // in the spill area (the literal walk of rays with zero / NaN direction components uses only that)
+            c->pair_levels = (std::max(depth, 1) + 2) & ~1;
+            int L = 12;
+            if (const char *e = getenv("PT_PAIR_LDS_LEVELS")) L = atoi(e);
+            c->pair_lds_levels = std::max(2, std::min(L, c->pair_levels));
+            c->pair_max_blocks = (((long)c->n_cu * 8 + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;
+            // two areas: an any-hit and a closest-hit launch may run at the same time (two streams of one render)
+            HIPCHK(c, hipMalloc(&c->d_spill, 2 * pt_trace_pair_spill_bytes(c->pair_levels, c->pair_max_blocks * 256)));
+        }
     }
     HIPCHK(c, upload(&c->d_nodes, nodes.data(), nodes.size()));
     // top of the tree for k_trace_top: the first K nodes in breadth-first order, K from the LDS left
@@ -551,6 +605,7 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     if (d->tri_uv && d->n_tris > 0) HIPCHK(c, upload(&c->d_uv, d->tri_uv, 6 * (size_t)d->n_tris));
     DScene &s = c->sc;
     s.nodes = (const GNode *)c->d_nodes;
+    s.pairs = (const GPair *)c->d_pairs;
     s.top = n_top ? (const TopNode *)c->d_top : nullptr;
     s.n_top = n_top;
     s.exact_slab = 0;
@@ -573,6 +628,7 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     memcpy(s.le_sum, le, sizeof(le));
     c->stack_need = std::max(depth, 1);
     c->trace_occ[0] = c->trace_occ[1] = 0;
+    c->pair_occ[0] = c->pair_occ[1] = 0;
     c->has_spec_reflect = spec;
     c->shadow_per_vertex_direct = spv;
     c->have_scene = true;
@@ -609,6 +665,32 @@ static int trace_grid(pt_ctx *c, long n, bool any) {
 static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t stream, const double *rays, long stride,
                                const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t, double *out_b1,
                                double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
+    // children-pair walk (PT_TRACE_PAIR: bit 0 = closest-hit launches, bit 1 = any-hit launches; unset: by tree size)
+    // Measured (profiles/r02_*): head mesh (5.5 k nodes, tree L1/L2-resident, k_trace_meta
+    // applies) closest 40.7 -> 45.7 ms, any 20.5 -> 20.5 ms: off; head_loop (352 k nodes) closest 2.1 -> 1.4 ms, any
+    // 3.3 -> 2.7 ms; 10^6-triangle soup (2 M nodes) closest 114 -> 88 ms, any 61 -> 42 ms: on for trees whose
+    // child words do not fit in LDS.
+    int use_pair = c->use_pair;
+    if (use_pair < 0) use_pair = c->meta_stack > 0 ? 0 : 3;
+    if (c->d_pairs && c->n_pairs > 0 && c->d_spill && (use_pair & (any ? 2 : 1))) {
+        int &occ = c->pair_occ[any ? 1 : 0];
+        if (occ == 0) {
+            occ = pt_trace_pair_occupancy(any, c->pair_lds_levels);
+            // the occupancy API counts LDS to the byte; a grid one block per CU too large leaves a partial second
+            // residency round (measured: 32 KB stacks, API 5, 117 vs 88 ms): keep a margin
+            const long by_lds = ((long)160 * 1024 - 4096) / (long)std::max<size_t>(pt_trace_pair_lds(c->pair_lds_levels), 1);
+            occ = (int)std::max<long>(1, std::min<long>(occ, by_lds));
+        }
+        long per_cu = occ;
+        if (const char *e = getenv("PT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1l, atol(e));
+        const long blocks = (n_bound + 255) / 256;
+        long grid = std::max<long>(1, std::min<long>(blocks, (long)c->n_cu * per_cu));
+        if (seg_counts) grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
+        grid = std::min<long>(grid, c->pair_max_blocks);                                        // what the spill area holds
+        char *spill = (char *)c->d_spill + (any ? pt_trace_pair_spill_bytes(c->pair_levels, c->pair_max_blocks * 256) : 0);
+        return pt_launch_trace_pair(any, c->pair_lds_levels, spill, (int)grid, stream, c->sc, rays, stride, seg_counts,
+                                    seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    }
     if (c->meta_stack > 0 && c->use_top <= 0 && (c->use_meta > 1 || (c->use_meta == 1 && !any))) {
         const long blocks = (n_bound + 1023) / 1024;
         const int grid = (int)std::max<long>(1, std::min<long>(blocks, c->n_cu));

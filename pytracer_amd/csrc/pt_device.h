@@ -83,8 +83,23 @@ struct __attribute__((aligned(16))) GTri {    // 80 B; p1 and the two edges of t
     double p1[3];
     double e1[3];        // p2 - p1 (same subtraction, done once on the host in binary64)
     double e2[3];        // p3 - p1
-    double _pad;
+    int32_t leaf_nprim;  // on the FIRST triangle of a leaf: that leaf's n_prim and node index (0 elsewhere); the
+    int32_t leaf_node;   // children-pair walk reaches a leaf by its first primitive alone (GPair::ref)
 };
+
+// Children-pair record of an interior node (k_trace_pair): ONE 128-byte line brings the boxes of both children,
+// so a step of the walk tests two boxes per dependent fetch instead of one (the visit ORDER, every comparison and
+// the census stay those of bvh.py:322-410: the far child's verdict is finished when it is popped).
+struct __attribute__((aligned(128))) GPair {
+    double b0[6];        // first child (node self + 1): bmin xyz, bmax xyz
+    double b1[6];        // second child (node nodes[self].offset)
+    int32_t ref0, ref1;  // child reference: >= 0 pair index of an interior child; < 0: ~(first primitive) of a leaf
+    int32_t axis;        // split axis of THIS node (dir_is_neg[node.axis], bvh.py:350)
+    int32_t self;        // this node's index in DScene::nodes (the exact re-test of a popped entry reads its box there)
+    int32_t node0, node1;// node indices of the two children
+    int32_t _pad[2];
+};
+static_assert(sizeof(GPair) == 128, "one cache line");
 
 // Top-of-tree record staged in LDS by k_trace_top (pt_kernels.hip): a GNode whose padding holds
 // the references of its two children.  ref >= 0: index into DScene::nodes; ref < 0: LDS slot ~ref.
@@ -113,6 +128,7 @@ struct BrdfGrid {
 
 struct DScene {
     const GNode *nodes;
+    const GPair *pairs;        // one record per interior node, numbered in depth-first order (root = 0), or nullptr
     const TopNode *top;        // the first n_top nodes in breadth-first order, or nullptr
     int32_t n_top;
     int32_t exact_slab;        // a node box with min > max (or NaN): only the reference's own comparison order is exact

@@ -123,6 +123,15 @@ hipError_t pt_launch_trace_top(bool any, int stack, int grid, hipStream_t stream
                                long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                                double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 size_t pt_trace_top_lds(int stack, int n_top);
+// k_trace_pair: the walk fetched by parent (GPair records); `stack` todo levels of 8-byte entries in LDS
+size_t pt_trace_pair_lds(int lds_levels);
+size_t pt_trace_pair_spill_bytes(int levels, long grid_threads);
+int pt_trace_pair_occupancy(bool any, int lds_levels);
+// grid must already be a whole number of PT_SEG-wave sets for segmented input (the caller sized `spill` for it)
+hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid, hipStream_t stream, const DScene &sc,
+                                const double *rays, long stride, const int *seg_counts, long seg, int n_val, int *out_prim,
+                                double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
+                                unsigned long long *counters);
 hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, int gshift,
                             const Queue &q, const PathState &st, unsigned long long *counters);
 hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, const HitList &hl);

@@ -90,7 +90,7 @@ __device__ __forceinline__ bool slab_hit(const double2 n0, const double2 n1, con
 // every accepted closest hit (aggregate/primitive.py:107).
 template <bool ANY, bool FAST>
 __device__ __forceinline__ int traverse_loop(const DScene &sc, Ray &r, const SlabRay &sv, int *stack, double &b1o,
-                                             double &b2o, unsigned &nvis, unsigned &ntri) {
+                                             double &b2o, unsigned &nvis, unsigned &ntri, const long STRIDE = PT_BLOCK) {
     int result = ANY ? 0 : -1;
     int todo_idx = 0, node_idx = 0;
     for (;;) {
@@ -118,7 +118,7 @@ __device__ __forceinline__ int traverse_loop(const DScene &sc, Ray &r, const Sla
         const bool neg = (sv.negmask >> (meta.y >> 16)) & 1;          // dir_is_neg[node.axis], bvh.py:350
         const int next = node_idx + 1;
         if (!inner && todo_idx == 0) break;
-        int *slot = stack + (inner ? todo_idx : todo_idx - 1) * PT_BLOCK;
+        int *slot = stack + (inner ? todo_idx : todo_idx - 1) * STRIDE;
         if (inner) *slot = neg ? next : meta.x;
         const int popped = *slot;
         node_idx = inner ? (neg ? meta.x : next) : popped;
@@ -165,29 +165,52 @@ __device__ __forceinline__ void trace_count(unsigned long long *counters, unsign
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 5   // <= 96 VGPRs: the two loops of traverse<> spill at 80 (6 waves/SIMD measured slower)
 #endif
-template <bool ANY>
-__device__ __forceinline__ void trace_one(const DScene &sc, const double *__restrict__ rays, long stride, long i,
-                                          int *stack, int *__restrict__ out_prim, double *__restrict__ out_t,
-                                          double *__restrict__ out_b1, double *__restrict__ out_b2,
-                                          const ShadowResolve &rs, unsigned &nvis, unsigned &ntri) {
+__device__ __forceinline__ Ray load_ray(const double *__restrict__ rays, long stride, long i) {
     Ray r;
     r.o = mk3(rays[i], rays[stride + i], rays[2 * stride + i]);
     r.d = mk3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
     r.mint = rays[6 * stride + i];
     r.maxt = rays[7 * stride + i];
-    double b1 = 0., b2 = 0.;
-    int res = traverse<ANY>(sc, r, stack, b1, b2, nvis, ntri);
-    if (out_prim) out_prim[i] = res;
+    return r;
+}
+// what every trace kernel does with a finished ray: hit record (closest) or the fused shadow resolve (any hit)
+struct TraceOut {
+    int *__restrict__ prim;
+    double *__restrict__ t, *__restrict__ b1, *__restrict__ b2;
+    ShadowResolve rs;
+};
+template <bool ANY>
+__device__ __forceinline__ void store_result(const TraceOut &o, long i, int res, const Ray &r, double b1, double b2) {
+    if (o.prim) o.prim[i] = res;
     if (!ANY) {
-        if (out_t) out_t[i] = r.maxt;
-        if (out_b1) out_b1[i] = b1;
-        if (out_b2) out_b2[i] = b2;
-    } else if (rs.L && res == 0) {
-        const int slot = rs.slot[i];
-        unsafeAtomicAdd(rs.L + slot, rs.c[i]);
-        unsafeAtomicAdd(rs.L + rs.lstride + slot, rs.c[rs.cstride + i]);
-        unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + i]);
+        if (o.t) o.t[i] = r.maxt;
+        if (o.b1) o.b1[i] = b1;
+        if (o.b2) o.b2[i] = b2;
+    } else if (o.rs.L && res == 0) {
+        const int slot = o.rs.slot[i];
+        unsafeAtomicAdd(o.rs.L + slot, o.rs.c[i]);
+        unsafeAtomicAdd(o.rs.L + o.rs.lstride + slot, o.rs.c[o.rs.cstride + i]);
+        unsafeAtomicAdd(o.rs.L + 2 * o.rs.lstride + slot, o.rs.c[2 * o.rs.cstride + i]);
     }
+}
+// The rays one thread serves, in both input shapes (below); returns how many.
+template <int BLOCK, class F>
+__device__ __forceinline__ unsigned for_each_ray(const int *__restrict__ seg_counts, long seg, int n_val, F one) {
+    unsigned nray = 0;
+    if (seg_counts) {
+        const int lane = threadIdx.x & 63;
+        const int wave = (int)((blockIdx.x * BLOCK + threadIdx.x) >> 6);
+        const int nsub = (int)((gridDim.x * (BLOCK / 64)) / PT_SEG);
+        const int r = wave % PT_SEG, sub = wave / PT_SEG;
+        if (sub < nsub) {
+            const int n = seg_counts[r * PT_CNT_STRIDE];
+            const long first = (long)r * seg;
+            for (int k = sub * 64 + lane; k < n; k += nsub * 64) { one(first + k); nray++; }
+        }
+    } else {
+        for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * BLOCK) { one(i); nray++; }
+    }
+    return nray;
 }
 
 // Two input shapes:
@@ -205,27 +228,14 @@ __global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, c
                                                     double *__restrict__ out_b1, double *__restrict__ out_b2,
                                                     ShadowResolve rs, unsigned long long *counters) {
     __shared__ int s_stack[STACK * PT_BLOCK];
-    unsigned nvis = 0, ntri = 0, nray = 0;
-    if (seg_counts) {
-        const int lane = threadIdx.x & 63;
-        const int wave = (int)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6);
-        const int nsub = (int)((gridDim.x * (PT_BLOCK / 64)) / PT_SEG);
-        const int r = wave % PT_SEG, sub = wave / PT_SEG;
-        if (sub < nsub) {
-            const int n = seg_counts[r * PT_CNT_STRIDE];
-            const long first = (long)r * seg;
-            for (int k = sub * 64 + lane; k < n; k += nsub * 64) {
-                trace_one<ANY>(sc, rays, stride, first + k, s_stack + threadIdx.x, out_prim, out_t, out_b1, out_b2, rs,
-                               nvis, ntri);
-                nray++;
-            }
-        }
-    } else {
-        for (long i = (long)blockIdx.x * PT_BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * PT_BLOCK) {
-            trace_one<ANY>(sc, rays, stride, i, s_stack + threadIdx.x, out_prim, out_t, out_b1, out_b2, rs, nvis, ntri);
-            nray++;
-        }
-    }
+    unsigned nvis = 0, ntri = 0;
+    const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
+    const unsigned nray = for_each_ray<PT_BLOCK>(seg_counts, seg, n_val, [&](long i) {
+        Ray r = load_ray(rays, stride, i);
+        double b1 = 0., b2 = 0.;
+        const int res = traverse<ANY>(sc, r, s_stack + threadIdx.x, b1, b2, nvis, ntri);
+        store_result<ANY>(out, i, res, r, b1, b2);
+    });
     if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
 }
 
@@ -307,41 +317,14 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_top(DScene sc, const dou
         for (int k = threadIdx.x; k < sc.n_top * 4; k += PT_TOP_BLOCK) dst[k] = src[k];
     }
     __syncthreads();
-    unsigned nvis = 0, ntri = 0, nray = 0;
-    auto one = [&](long i) {
-        Ray r;
-        r.o = mk3(rays[i], rays[stride + i], rays[2 * stride + i]);
-        r.d = mk3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
-        r.mint = rays[6 * stride + i];
-        r.maxt = rays[7 * stride + i];
+    unsigned nvis = 0, ntri = 0;
+    const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
+    const unsigned nray = for_each_ray<PT_TOP_BLOCK>(seg_counts, seg, n_val, [&](long i) {
+        Ray r = load_ray(rays, stride, i);
         double b1 = 0., b2 = 0.;
         const int res = traverse_top<ANY>(sc, top, r, stack, b1, b2, nvis, ntri);
-        if (out_prim) out_prim[i] = res;
-        if (!ANY) {
-            if (out_t) out_t[i] = r.maxt;
-            if (out_b1) out_b1[i] = b1;
-            if (out_b2) out_b2[i] = b2;
-        } else if (rs.L && res == 0) {
-            const int slot = rs.slot[i];
-            unsafeAtomicAdd(rs.L + slot, rs.c[i]);
-            unsafeAtomicAdd(rs.L + rs.lstride + slot, rs.c[rs.cstride + i]);
-            unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + i]);
-        }
-        nray++;
-    };
-    if (seg_counts) {
-        const int lane = threadIdx.x & 63;
-        const int wave = (int)((blockIdx.x * PT_TOP_BLOCK + threadIdx.x) >> 6);
-        const int nsub = (int)((gridDim.x * (PT_TOP_BLOCK / 64)) / PT_SEG);
-        const int r = wave % PT_SEG, sub = wave / PT_SEG;
-        if (sub < nsub) {
-            const int n = seg_counts[r * PT_CNT_STRIDE];
-            const long first = (long)r * seg;
-            for (int k = sub * 64 + lane; k < n; k += nsub * 64) one(first + k);
-        }
-    } else {
-        for (long i = (long)blockIdx.x * PT_TOP_BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * PT_TOP_BLOCK) one(i);
-    }
+        store_result<ANY>(out, i, res, r, b1, b2);
+    });
     if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
 }
 
@@ -400,13 +383,10 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_meta(DScene sc, const do
     for (int k = threadIdx.x; k < sc.n_nodes; k += PT_TOP_BLOCK)
         mlds[k] = make_int2(sc.nodes[k].offset, sc.nodes[k].nprim_axis);
     __syncthreads();
-    unsigned nvis = 0, ntri = 0, nray = 0;
-    auto one = [&](long i) {
-        Ray r;
-        r.o = mk3(rays[i], rays[stride + i], rays[2 * stride + i]);
-        r.d = mk3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
-        r.mint = rays[6 * stride + i];
-        r.maxt = rays[7 * stride + i];
+    unsigned nvis = 0, ntri = 0;
+    const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
+    const unsigned nray = for_each_ray<PT_TOP_BLOCK>(seg_counts, seg, n_val, [&](long i) {
+        Ray r = load_ray(rays, stride, i);
         double b1 = 0., b2 = 0.;
         int res = ANY ? 0 : -1;
         if (sc.n_nodes > 0) {
@@ -414,33 +394,235 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_meta(DScene sc, const do
             res = sv.fast ? traverse_meta_loop<ANY, true>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri)
                           : traverse_meta_loop<ANY, false>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri);
         }
-        if (out_prim) out_prim[i] = res;
-        if (!ANY) {
-            if (out_t) out_t[i] = r.maxt;
-            if (out_b1) out_b1[i] = b1;
-            if (out_b2) out_b2[i] = b2;
-        } else if (rs.L && res == 0) {
-            const int slot = rs.slot[i];
-            unsafeAtomicAdd(rs.L + slot, rs.c[i]);
-            unsafeAtomicAdd(rs.L + rs.lstride + slot, rs.c[rs.cstride + i]);
-            unsafeAtomicAdd(rs.L + 2 * rs.lstride + slot, rs.c[2 * rs.cstride + i]);
-        }
-        nray++;
-    };
-    if (seg_counts) {
-        const int lane = threadIdx.x & 63;
-        const int wave = (int)((blockIdx.x * PT_TOP_BLOCK + threadIdx.x) >> 6);
-        const int nsub = (int)((gridDim.x * (PT_TOP_BLOCK / 64)) / PT_SEG);
-        const int r = wave % PT_SEG, sub = wave / PT_SEG;
-        if (sub < nsub) {
-            const int n = seg_counts[r * PT_CNT_STRIDE];
-            const long first = (long)r * seg;
-            for (int k = sub * 64 + lane; k < n; k += nsub * 64) one(first + k);
-        }
-    } else {
-        for (long i = (long)blockIdx.x * PT_TOP_BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * PT_TOP_BLOCK) one(i);
-    }
+        store_result<ANY>(out, i, res, r, b1, b2);
+    });
     if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
+}
+
+// ---- children pairs -------------------------------------------------------------------------
+// k_trace_pair: the same walk (bvh.py:322-410), fetched by PARENT: the record of an interior node (GPair, one
+// 128-byte line) holds the boxes of both children, so one dependent fetch decides two visits.  What keeps it the
+// reference's walk, visit for visit:
+//  * the near child (dir_is_neg[axis], bvh.py:350) is visited at once with the ray as it is;
+//  * the far child is visited when the reference pops it.  Of its box test, `tnear <= tfar` and `tfar > mint` can
+//    never change; `tnear < maxt` can (closest hit only: accepted hits shrink maxt) and is finished at the pop.
+//    The stack entry carries the HIGH WORD of the binary64 tnear: that bounds tnear between two doubles, which
+//    settles the comparison unless maxt falls between them — then the child's own box is fetched and the
+//    comparison made exactly (exact_tnear_lt_maxt).  A far child whose verdict is already "miss" is counted, not
+//    pushed;
+//  * any hit: maxt never changes, so only hit far children are pushed; the visits of the others are counted when
+//    the reference would pop them (`pend`: missed far children above the top stack entry; each entry remembers
+//    how many lie under it), because an any-hit walk returns at its first hit and never visits what is left.
+// Rays that need the literal slab test (zero / NaN direction components, unordered boxes) walk the node array
+// with traverse_loop<ANY, false> as before.
+struct PairEnt { int ref; int aux; };   // aux: closest = high word of tnear; any = missed far children under the entry
+#define PT_PAIR_POP (-0x7fffffff - 1)
+
+__device__ __forceinline__ bool exact_tnear_lt_maxt(const DScene &sc, int ref, const Ray &r, double invx, double invy,
+                                                    double invz) {
+    const int node = ref >= 0 ? sc.pairs[ref].self : sc.tris[~ref].leaf_node;
+    const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node);
+    const double2 n0 = q[0], n1 = q[1], n2 = q[2];
+    const double x0 = (n0.x - r.o.x) * invx, x1 = (n1.y - r.o.x) * invx;
+    const double y0 = (n0.y - r.o.y) * invy, y1 = (n2.x - r.o.y) * invy;
+    const double z0 = (n1.x - r.o.z) * invz, z1 = (n2.y - r.o.z) * invz;
+    const double tnear = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+    return tnear < r.maxt;
+}
+
+// The todo stack is split: levels [0, L) in LDS (stack[level][thread]), levels from L on in a global spill area
+// (spill[level - L][grid thread], coalesced across a wave's lanes) — deep trees would otherwise take 8 bytes x depth
+// of LDS per lane and leave two or three waves per SIMD to hide a latency-bound walk.
+struct PairStack {
+    PairEnt *lds;        // + thread
+    PairEnt *spill;      // + grid thread
+    long spill_stride;   // grid threads
+    int L;
+};
+template <int BLOCK>
+__device__ __forceinline__ void pair_push(const PairStack &st, int level, PairEnt e) {
+    if (level < st.L) st.lds[level * BLOCK] = e;
+    else st.spill[(long)(level - st.L) * st.spill_stride] = e;
+}
+template <int BLOCK>
+__device__ __forceinline__ PairEnt pair_pop(const PairStack &st, int level) {
+    if (level < st.L) return st.lds[level * BLOCK];
+    return st.spill[(long)(level - st.L) * st.spill_stride];
+}
+
+template <bool ANY, int BLOCK>
+__device__ __forceinline__ int traverse_pair_loop(const DScene &sc, Ray &r, const SlabRay &sv, const PairStack &stack,
+                                                  double &b1o, double &b2o, unsigned &nvis, unsigned &ntri) {
+    int result = ANY ? 0 : -1;
+    int ref;
+    {   // the root: a visit like any other
+        const double2 *q = reinterpret_cast<const double2 *>(sc.nodes);
+        const double2 n0 = q[0], n1 = q[1], n2 = q[2];
+        const int2 meta = *reinterpret_cast<const int2 *>(&q[3]);
+        nvis++;
+        if (!slab_hit<true>(n0, n1, n2, r, sv)) return result;
+        ref = (meta.y & 0xFFFF) ? ~meta.x : 0;
+    }
+    int todo = 0;
+    unsigned pend = 0;
+    for (;;) {
+        int next;
+        if (ref < 0) {
+            // a leaf whose box was hit: its primitives in order (bvh.py:339-345 / :384-390)
+            const int first = ~ref;
+            int n = 1;
+            for (int i = 0; i < n; i++) {
+                const double2 *q = reinterpret_cast<const double2 *>(sc.tris + first + i);
+                const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+                if (i == 0) n = __double2loint(a4.y);          // GTri::leaf_nprim
+                double t, b1, b2;
+                ntri++;
+                if (tri_math(a0, a1, a2, a3, a4, r, t, b1, b2)) {
+                    if (ANY) return 1;
+                    result = first + i;
+                    b1o = b1; b2o = b2;
+                    r.maxt = t;
+                }
+            }
+            next = PT_PAIR_POP;
+        } else {
+            const double2 *q = reinterpret_cast<const double2 *>(sc.pairs + ref);
+            const double2 c0 = q[0], c1 = q[1], c2 = q[2], d0 = q[3], d1 = q[4], d2 = q[5];
+            const int4 m = *reinterpret_cast<const int4 *>(&q[6]);         // ref0, ref1, axis, self
+            // both slab tests in the fast form (slab_hit<true>)
+            const double ax0 = (c0.x - r.o.x) * sv.invx, ax1 = (c1.y - r.o.x) * sv.invx;
+            const double ay0 = (c0.y - r.o.y) * sv.invy, ay1 = (c2.x - r.o.y) * sv.invy;
+            const double az0 = (c1.x - r.o.z) * sv.invz, az1 = (c2.y - r.o.z) * sv.invz;
+            const double bx0 = (d0.x - r.o.x) * sv.invx, bx1 = (d1.y - r.o.x) * sv.invx;
+            const double by0 = (d0.y - r.o.y) * sv.invy, by1 = (d2.x - r.o.y) * sv.invy;
+            const double bz0 = (d1.x - r.o.z) * sv.invz, bz1 = (d2.y - r.o.z) * sv.invz;
+            const double tn0 = fmax(fmax(fmin(ax0, ax1), fmin(ay0, ay1)), fmin(az0, az1));
+            const double tf0 = fmin(fmin(fmax(ax0, ax1), fmax(ay0, ay1)), fmax(az0, az1));
+            const double tn1 = fmax(fmax(fmin(bx0, bx1), fmin(by0, by1)), fmin(bz0, bz1));
+            const double tf1 = fmin(fmin(fmax(bx0, bx1), fmax(by0, by1)), fmax(bz0, bz1));
+            const bool ok0 = (tn0 <= tf0) && (tn0 < r.maxt) && (tf0 > r.mint);
+            const bool ok1 = (tn1 <= tf1) && (tn1 < r.maxt) && (tf1 > r.mint);
+            const bool neg = (sv.negmask >> m.z) & 1;                       // near child = second child when negative
+            const bool okN = neg ? ok1 : ok0, okF = neg ? ok0 : ok1;
+            const int refN = neg ? m.y : m.x, refF = neg ? m.x : m.y;
+            nvis++;                                                         // the near child's visit
+            if (okN) {
+                if (okF) {
+                    PairEnt e;
+                    e.ref = refF;
+                    e.aux = ANY ? (int)pend : __double2hiint(neg ? tn0 : tn1);
+                    pair_push<BLOCK>(stack, todo, e);
+                    todo++;
+                    pend = 0;
+                } else if (ANY) pend++;
+                else nvis++;                                                // closest: it will be popped and missed
+                next = refN;
+            } else {
+                nvis++;                                                     // the far child is popped right away
+                next = okF ? refF : PT_PAIR_POP;
+            }
+        }
+        if (next == PT_PAIR_POP) {
+            if (ANY) {
+                nvis += pend;
+                if (todo == 0) break;
+                todo--;
+                const PairEnt e = pair_pop<BLOCK>(stack, todo);
+                nvis++;
+                pend = (unsigned)e.aux;
+                next = e.ref;
+            } else {
+                for (;;) {
+                    if (todo == 0) { next = PT_PAIR_POP; break; }
+                    todo--;
+                    const PairEnt e = pair_pop<BLOCK>(stack, todo);
+                    nvis++;
+                    // tnear lies between the two doubles that share its high word
+                    const double lo = __hiloint2double(e.aux, 0), hi = __hiloint2double(e.aux, (int)0xFFFFFFFF);
+                    const bool sure_hit = (r.maxt > lo) && (r.maxt > hi);
+                    const bool sure_miss = (r.maxt <= lo) && (r.maxt <= hi);
+                    bool hit = sure_hit;
+                    if (!sure_hit && !sure_miss) hit = exact_tnear_lt_maxt(sc, e.ref, r, sv.invx, sv.invy, sv.invz);
+                    if (hit) { next = e.ref; break; }
+                }
+                if (next == PT_PAIR_POP) break;
+            }
+        }
+        ref = next;
+    }
+    return result;
+}
+
+#define PT_PAIR_BLOCK 256
+#ifndef PT_PAIR_WAVES
+#define PT_PAIR_WAVES 4
+#endif
+template <bool ANY>
+__global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair(DScene sc, const double *__restrict__ rays, long stride,
+                                                             const int *__restrict__ seg_counts, long seg, int n_val,
+                                                             int *__restrict__ out_prim, double *__restrict__ out_t,
+                                                             double *__restrict__ out_b1, double *__restrict__ out_b2,
+                                                             ShadowResolve rs, unsigned long long *counters,
+                                                             PairEnt *__restrict__ spill, int lds_levels) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    PairStack stack;
+    stack.lds = reinterpret_cast<PairEnt *>(s_mem) + threadIdx.x;            // stack[level][thread], 8-byte entries
+    stack.spill = spill + ((long)blockIdx.x * PT_PAIR_BLOCK + threadIdx.x);
+    stack.spill_stride = (long)gridDim.x * PT_PAIR_BLOCK;
+    stack.L = lds_levels;
+    unsigned nvis = 0, ntri = 0;
+    const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
+    const unsigned nray = for_each_ray<PT_PAIR_BLOCK>(seg_counts, seg, n_val, [&](long i) {
+        Ray r = load_ray(rays, stride, i);
+        double b1 = 0., b2 = 0.;
+        int res = ANY ? 0 : -1;
+        if (sc.n_nodes > 0) {
+            const SlabRay sv = slab_ray(sc, r);
+            if (sv.fast) res = traverse_pair_loop<ANY, PT_PAIR_BLOCK>(sc, r, sv, stack, b1, b2, nvis, ntri);
+            else   // the literal walk keeps its whole stack in the spill area (one int per level)
+                res = traverse_loop<ANY, false>(sc, r, sv, reinterpret_cast<int *>(stack.spill), b1, b2, nvis, ntri,
+                                                2 * stack.spill_stride);
+        }
+        store_result<ANY>(out, i, res, r, b1, b2);
+    });
+    if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
+}
+
+size_t pt_trace_pair_lds(int lds_levels) { return (size_t)lds_levels * PT_PAIR_BLOCK * sizeof(PairEnt); }
+size_t pt_trace_pair_spill_bytes(int levels, long grid_threads) { return (size_t)levels * (size_t)grid_threads * sizeof(PairEnt); }
+
+int pt_trace_pair_occupancy(bool any, int lds_levels) {
+    int nb = 0;
+    if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pair<true>, PT_PAIR_BLOCK, pt_trace_pair_lds(lds_levels));
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pair<false>, PT_PAIR_BLOCK, pt_trace_pair_lds(lds_levels));
+    return nb > 0 ? nb : 2;
+}
+
+// `spill` must hold pt_trace_pair_spill_bytes(tree levels, grid x 256): every level for the rays that take the
+// literal walk, the levels from lds_levels on for the others.
+hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid, hipStream_t stream, const DScene &sc,
+                                const double *rays, long stride, const int *seg_counts, long seg, int n_val, int *out_prim,
+                                double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
+                                unsigned long long *counters) {
+    static bool attr_set[PT_MAX_DEVICES][2];
+    const size_t lds = pt_trace_pair_lds(lds_levels);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!attr_set[dev][any ? 1 : 0]) {
+        hipError_t e = any ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_pair<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_pair<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[dev][any ? 1 : 0] = true;
+    }
+    if (any)
+        hipLaunchKernelGGL((k_trace_pair<true>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride, seg_counts,
+                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels);
+    else
+        hipLaunchKernelGGL((k_trace_pair<false>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride, seg_counts,
+                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels);
+    return hipGetLastError();
 }
 
 size_t pt_trace_meta_lds(int stack, int n_nodes) {

@@ -22,13 +22,31 @@ def main():
     ap.add_argument('--res', type=int, default=1024)
     ap.add_argument('--spp', type=int, default=8)
     ap.add_argument('--integrator', default='path')
+    ap.add_argument('--workload', choices=['head', 'c2', 'c4', 'c5'], default='head')
     args = ap.parse_args()
     import torch
     import pytracer_amd as pa
     from pytracer_amd import _abi as A, host
     from pytracer_amd._lib import Context
-    d = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'head_mesh_scene.npz')))
-    flat = pa.flat_scene_from_npz(d)
+    from pytracer_amd import workloads
+    G = os.path.join(ROOT, 'tests', 'golden')
+    xres = yres = args.res
+    ys = args.spp
+    if args.workload == 'head':
+        flat = pa.flat_scene_from_npz(dict(np.load(os.path.join(G, 'head_mesh_scene.npz'))))
+    elif args.workload == 'c2':
+        flat = workloads.c2_head_loop(os.path.join(G, 'c2_head_loop.npz'), os.path.join(G, 'loop_subdiv.npz'))
+        xres = yres = 512 if args.res == 1024 else args.res
+        args.spp = ys = 4 if args.spp == 8 else args.spp
+        args.integrator = 'direct'
+    elif args.workload == 'c5':
+        flat = workloads.c5_head_measured(os.path.join(G, 'head_mesh_scene.npz'))
+        args.spp = 16 if args.spp == 8 else args.spp
+        ys = max(args.spp // 2, 1)
+    else:
+        flat = workloads.c4_soup()
+        xres, yres = 1920, 1080
+        args.spp = ys = 4 if args.spp == 8 else args.spp
     arms = []
     for e in args.env or ['']:
         kv = dict(x.split('=') for x in e.split(',') if x)
@@ -39,11 +57,12 @@ def main():
         for k in kv:
             del os.environ[k]
         arms.append((e, c))
-    cam, film = host.head_mesh_camera_film(args.res, args.res)
+    cam, film = (workloads.c4_camera_film(xres, yres) if args.workload == 'c4'
+                 else host.head_mesh_camera_film(xres, yres))
     kind = A.PT_INTEG_PATH if args.integrator == 'path' else A.PT_INTEG_DIRECT
     integ = pa.integrator_desc(kind, 5, False)
-    smp = pa.sampler_desc(0, args.res, 0, args.res, args.spp, args.spp, True, 0)
-    tile = pa.tile_desc(0, args.res, 0, args.res, 0, args.spp ** 2)
+    smp = pa.sampler_desc(0, xres, 0, yres, args.spp, ys, True, 0)
+    tile = pa.tile_desc(0, xres, 0, yres, 0, args.spp * ys)
     acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
     sums = {}
     for rnd in range(args.rounds + 1):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 (rocpd sqlite) outputs into the tracked files under profiles/.
 
-    python3 tools/prof_summary.py <round-tag> <stats.db> [<fetch.db> <write.db>]
+    python3 tools/prof_summary.py <round-tag> <stats.db> [<fetch.db> <write.db> [headline]]
 
 Writes profiles/<tag>_kernel_stats.csv (the `--kernel-trace --stats` table) and, when the two
 PMC passes are given, profiles/<tag>_pmc.csv plus profiles/pmc_summary.json, which bench.py
@@ -24,7 +24,7 @@ def short(name):
     m = re.match(r'(?:void )?(k_trace)<(\d+), (true|false)>', name)
     if m:
         return 'k_trace<%s>' % ('any' if m.group(3) == 'true' else 'closest')
-    m = re.match(r'(?:void )?k_trace_(?:meta|top)<(true|false)>', name)   # LDS-staged variants of the same walk
+    m = re.match(r'(?:void )?k_trace_(?:meta|top|pair|lds)<(true|false)>', name)   # other fetch forms of the same walk
     if m:
         return 'k_trace<%s>' % ('any' if m.group(1) == 'true' else 'closest')
     m = re.match(r'(?:void )?k_shade<(\d+), (\d+|true|false)>', name)    # second argument: 1 textures / uvs, 2 measured BRDF
@@ -75,7 +75,18 @@ def main():
                 w.writerow([k, n, '%.1f' % fk, '%.1f' % wk, '%.0f' % per])
                 summary[k] = {'launches': n, 'fetch_kb_total': fk, 'write_kb_total': wk, 'hbm_bytes_per_launch': per,
                               'source': 'profiles/%s_pmc.csv' % tag}
-        json.dump(summary, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
+        if len(sys.argv) >= 6 and sys.argv[5] == 'headline':       # only the headline workload feeds bench.py's roofline.traffic
+            import subprocess
+            import time
+            try:
+                commit = subprocess.check_output(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD']).decode().strip()
+                dirty = bool(subprocess.check_output(['git', '-C', ROOT, 'status', '--porcelain', '--', 'pytracer_amd/csrc']).strip())
+            except Exception:
+                commit, dirty = None, None
+            summary['_meta'] = {'commit': commit, 'kernel_sources_modified_since_commit': dirty, 'tag': tag,
+                                'recorded': time.strftime('%Y-%m-%dT%H:%M:%SZ', time.gmtime()),
+                                'workload': 'bench.py default (head mesh 1024^2, 64 spp, Path)'}
+            json.dump(summary, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
 
 
 if __name__ == '__main__':
