@@ -22,9 +22,6 @@ struct pt_ctx {
     DScene sc;
     void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf;
     void *d_pairs;           // GPair records of the interior nodes (k_trace_pair)
-    void *d_lds_tree;        // packed image of a small tree (k_trace_lds)
-    LdsTree lds_tree;        // bytes = 0: the tree does not qualify
-    int use_lds;             // PT_TRACE_LDS: bit 0 closest-hit launches, bit 1 any-hit launches; unset (-1) = both when it qualifies
     int n_pairs;
     int use_pair;            // PT_TRACE_PAIR: 0 never, 1 always, unset (-1) = by tree size (launch_trace)
     size_t brdf_bytes;
@@ -161,8 +158,6 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     if (const char *e = getenv("PT_TRACE_META")) c->use_meta = atoi(e);
     c->use_pair = -1;
     if (const char *e = getenv("PT_TRACE_PAIR")) c->use_pair = atoi(e);
-    c->use_lds = -1;
-    if (const char *e = getenv("PT_TRACE_LDS")) c->use_lds = atoi(e);
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
     // + 4 words behind the census shards: the channel maxima of pt_film_to_u8
     CREATE_CHK(hipMalloc((void **)&c->d_counters, (PT_CNT_SHARDS * CNT_COUNT + 4) * sizeof(unsigned long long)));
@@ -220,7 +215,7 @@ static void collect_timing(pt_ctx *c, pt_stats *stats) {
 
 static void free_scene(pt_ctx *c) {
     void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top,
-                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill, &c->d_lds_tree};
+                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -427,52 +422,6 @@ static int upload_brdf_tables(pt_ctx *c, const pt_scene_desc *d, std::vector<pt_
     return PT_OK;
 }
 
-// The LDS image of a small tree (LdsTree, pt_device.h).  Returns false when the tree does not qualify: more than
-// 4096 interior nodes or primitives (12-bit references), more than 65536 distinct plane values on an axis, or an
-// image that leaves no room for the todo stacks.
-static bool build_lds_tree(const std::vector<GNode> &nodes, const std::vector<GPair> &pairs, int n_tris,
-                           std::vector<char> &blob, LdsTree &lt) {
-    memset(&lt, 0, sizeof(lt));
-    if (pairs.empty() || pairs.size() > 4096 || n_tris > 4096 || nodes.empty()) return false;
-    std::vector<uint64_t> dict[3];
-    auto key = [](double v) { uint64_t k; memcpy(&k, &v, 8); return k; };
-    for (const GNode &g : nodes)
-        for (int a = 0; a < 3; a++) { dict[a].push_back(key(g.bmin[a])); dict[a].push_back(key(g.bmax[a])); }
-    for (int a = 0; a < 3; a++) {
-        std::sort(dict[a].begin(), dict[a].end());
-        dict[a].erase(std::unique(dict[a].begin(), dict[a].end()), dict[a].end());
-        if (dict[a].size() > 65536) return false;
-    }
-    auto index_of = [&](int a, double v) {
-        return (uint16_t)(std::lower_bound(dict[a].begin(), dict[a].end(), key(v)) - dict[a].begin());
-    };
-    const size_t off_rec = sizeof(LdsTreeHead), off_dx = off_rec + pairs.size() * sizeof(LPair);
-    const size_t off_dy = off_dx + dict[0].size() * 8, off_dz = off_dy + dict[1].size() * 8;
-    const size_t bytes = (off_dz + dict[2].size() * 8 + 15) & ~(size_t)15;
-    if (bytes + 4 * 512 * 4 > (size_t)160 * 1024 - 1024) return false;       // not even four todo levels for 512 threads
-    blob.assign(bytes, 0);
-    LdsTreeHead *h = (LdsTreeHead *)blob.data();
-    memcpy(h->root, nodes[0].bmin, 3 * sizeof(double));
-    memcpy(h->root + 3, nodes[0].bmax, 3 * sizeof(double));
-    h->root_ref = (nodes[0].nprim_axis & 0xFFFF) ? (int32_t)(PT_LDS_REF_LEAF | (uint32_t)nodes[0].offset) : 0;
-    LPair *rec = (LPair *)(blob.data() + off_rec);
-    for (size_t i = 0; i < pairs.size(); i++) {
-        const GPair &p = pairs[i];
-        for (int k = 0; k < 6; k++) {
-            rec[i].b0[k] = index_of(k % 3, p.b0[k]);
-            rec[i].b1[k] = index_of(k % 3, p.b1[k]);
-        }
-        auto ref13 = [](int32_t r) { return r >= 0 ? (uint32_t)r : (PT_LDS_REF_LEAF | (uint32_t)~r); };
-        rec[i].meta = ref13(p.ref0) | (ref13(p.ref1) << 13) | ((uint32_t)p.axis << 26);
-        rec[i]._pad = 0;
-    }
-    for (int a = 0; a < 3; a++)
-        memcpy(blob.data() + (a == 0 ? off_dx : (a == 1 ? off_dy : off_dz)), dict[a].data(), dict[a].size() * 8);
-    lt.bytes = (int32_t)bytes;
-    lt.off_dx = (int32_t)off_dx; lt.off_dy = (int32_t)off_dy; lt.off_dz = (int32_t)off_dz;
-    return true;
-}
-
 static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     if (!c || !d) return PT_ERR_ARG;
     if (d->n_nodes < 0 || d->n_tris < 0 || d->n_materials < 0 || d->n_lights < 0) return fail(c, PT_ERR_ARG, "negative count");
@@ -552,7 +501,6 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
         const double *b = d->node_bounds + 6 * i;
         if (!(b[0] <= b[3]) || !(b[1] <= b[4]) || !(b[2] <= b[5])) exact_slab_scene = true;
     }
-    memset(&c->lds_tree, 0, sizeof(c->lds_tree));
     // children-pair records (k_trace_pair): interior nodes numbered in depth-first (= index) order, root = pair 0
     {
         std::vector<int32_t> pair_of((size_t)d->n_nodes, -1);
@@ -594,14 +542,6 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
             c->pair_max_blocks = (((long)c->n_cu * 8 + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;
             // two areas: an any-hit and a closest-hit launch may run at the same time (two streams of one render)
             HIPCHK(c, hipMalloc(&c->d_spill, 2 * pt_trace_pair_spill_bytes(c->pair_levels, c->pair_max_blocks * 256)));
-            // small trees: the packed image for k_trace_lds
-            std::vector<char> blob;
-            LdsTree lt;
-            if (!exact_slab_scene && build_lds_tree(nodes, pairs, d->n_tris, blob, lt)) {
-                HIPCHK(c, upload(&c->d_lds_tree, blob.data(), blob.size()));
-                lt.blob = c->d_lds_tree;
-                c->lds_tree = lt;
-            }
         }
     }
     HIPCHK(c, upload(&c->d_nodes, nodes.data(), nodes.size()));
@@ -674,7 +614,6 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     s.top = n_top ? (const TopNode *)c->d_top : nullptr;
     s.n_top = n_top;
     s.exact_slab = exact_slab_scene ? 1 : 0;
-    s.lds_tree = c->lds_tree;
     s.tris = (const GTri *)c->d_tris;
     s.tri_verts = (const double *)c->d_verts;
     s.tri_mat = (const int32_t *)c->d_mat;
@@ -727,22 +666,6 @@ static int trace_grid(pt_ctx *c, long n, bool any) {
 static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t stream, const double *rays, long stride,
                                const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t, double *out_b1,
                                double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
-    // the whole tree in LDS (small scenes)
-    {
-        int use_lds = c->use_lds;
-        if (use_lds < 0) use_lds = 0;
-        if (c->lds_tree.bytes > 0 && c->d_spill && (use_lds & (any ? 2 : 1))) {
-            const long blocks = (n_bound + PT_LDS_BLOCK - 1) / PT_LDS_BLOCK;
-            long grid = std::max<long>(1, std::min<long>(blocks, c->n_cu));
-            if (seg_counts) {   // whole sets of PT_SEG waves
-                const int per = PT_SEG / (PT_LDS_BLOCK / 64);
-                grid = ((grid + per - 1) / per) * per;
-            }
-            char *spill = (char *)c->d_spill + (any ? pt_trace_pair_spill_bytes(c->pair_levels, c->pair_max_blocks * 256) : 0);
-            return pt_launch_trace_lds(any, c->pair_levels, spill, (int)grid, stream, c->sc, rays, stride, seg_counts, seg,
-                                       n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
-        }
-    }
     // children-pair walk (PT_TRACE_PAIR: bit 0 = closest-hit launches, bit 1 = any-hit launches; unset: by tree size)
     // Measured (profiles/r02_*): head mesh (5.5 k nodes, tree L1/L2-resident, k_trace_meta
     // applies) closest 40.7 -> 45.7 ms, any 20.5 -> 20.5 ms: off; head_loop (352 k nodes) closest 2.1 -> 1.4 ms, any

@@ -101,32 +101,6 @@ struct __attribute__((aligned(128))) GPair {
 };
 static_assert(sizeof(GPair) == 128, "one cache line");
 
-// The whole tree in LDS (k_trace_lds, small scenes): every plane coordinate of every node box is one of the mesh's
-// vertex coordinates, so a box is stored as six 16-bit indices into per-axis dictionaries of the DISTINCT binary64
-// values (bit patterns) — the exact doubles come back from the dictionary, the comparisons stay the reference's.
-// One children-pair record = 32 bytes instead of GPair's 128, and a 5.5 k-node tree (2 768 records + ~1 400 values
-// per axis) takes ~120 KB of the CU's 160 KB.  Image (built by pt_scene_upload, copied by every workgroup):
-//   [LdsTreeHead 64 B][LPair x n_pairs][dict x][dict y][dict z]
-struct LPair {           // 32 B
-    uint16_t b0[6];      // first child: indices of bmin.x, bmin.y, bmin.z, bmax.x, bmax.y, bmax.z
-    uint16_t b1[6];      // second child
-    uint32_t meta;       // ref0 | ref1 << 13 | axis << 26; ref: bit 12 set = leaf, low 12 bits = pair index / first primitive
-    uint32_t _pad;
-};
-struct LdsTreeHead {     // 64 B
-    double root[6];      // the root's box
-    int32_t root_ref;    // the root as a 13-bit reference
-    int32_t _pad[3];
-};
-struct LdsTree {
-    const void *blob;    // device copy of the image
-    int32_t bytes;       // of the image (a multiple of 16); 0 = the tree does not qualify
-    int32_t off_dx, off_dy, off_dz;   // byte offsets of the dictionaries
-    int32_t lds_levels;  // todo levels kept in LDS (4-byte entries); deeper ones go to the spill area
-};
-#define PT_LDS_REF_LEAF 0x1000u
-#define PT_LDS_REF_MASK 0x1FFFu
-
 // Top-of-tree record staged in LDS by k_trace_top (pt_kernels.hip): a GNode whose padding holds
 // the references of its two children.  ref >= 0: index into DScene::nodes; ref < 0: LDS slot ~ref.
 struct __attribute__((aligned(16))) TopNode {   // 64 B
@@ -155,7 +129,6 @@ struct BrdfGrid {
 struct DScene {
     const GNode *nodes;
     const GPair *pairs;        // one record per interior node, numbered in depth-first order (root = 0), or nullptr
-    LdsTree lds_tree;          // the same records packed for LDS (small trees), bytes = 0 otherwise
     const TopNode *top;        // the first n_top nodes in breadth-first order, or nullptr
     int32_t n_top;
     int32_t exact_slab;        // a node box with min > max (or NaN): only the reference's own comparison order is exact

@@ -123,13 +123,6 @@ hipError_t pt_launch_trace_top(bool any, int stack, int grid, hipStream_t stream
                                long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                                double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 size_t pt_trace_top_lds(int stack, int n_top);
-// k_trace_lds: the whole tree (DScene::lds_tree) in LDS, one PT_LDS_BLOCK-thread workgroup per CU; `levels` = todo
-// levels the tree needs; `spill` as for k_trace_pair (>= levels x grid x PT_LDS_BLOCK x 8 bytes)
-#define PT_LDS_BLOCK 512
-hipError_t pt_launch_trace_lds(bool any, int levels, void *spill, int grid, hipStream_t stream, const DScene &sc,
-                               const double *rays, long stride, const int *seg_counts, long seg, int n_val, int *out_prim,
-                               double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
-                               unsigned long long *counters);
 // k_trace_pair: the walk fetched by parent (GPair records); `stack` todo levels of 8-byte entries in LDS
 size_t pt_trace_pair_lds(int lds_levels);
 size_t pt_trace_pair_spill_bytes(int levels, long grid_threads);

@@ -4,8 +4,6 @@
 // → K2 trace_any (+K6 shadow resolve) → … → K7 film splat, K8 film resolve.
 // No MFMA anywhere: ray–box / ray–triangle tests and BSDF evaluation are not dense
 // contractions; the bounding resource is cache/HBM bandwidth and divergent fp64 VALU.
-#include <algorithm>
-
 #include "pt_kernels.h"
 
 // =========================================================================================
@@ -624,219 +622,6 @@ hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid,
     else
         hipLaunchKernelGGL((k_trace_pair<false>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride, seg_counts,
                            seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels);
-    return hipGetLastError();
-}
-
-// ---- the whole tree in LDS -----------------------------------------------------------------
-// k_trace_lds: for scenes whose packed tree (LdsTree, pt_device.h: 32-byte children-pair records of 16-bit indices
-// into per-axis dictionaries of the distinct plane values) fits in LDS beside the todo stacks.  One 512-thread
-// workgroup per CU copies the image once and then walks rays with NO vector-memory traffic per node visit: a step is
-// 2 ds_read_b128 (the record) + 12 ds_read_b64 (the planes, exact binary64 from the dictionary) — the vector-memory
-// lane-request rate that bounds every global-memory form of the walk is out of the loop; only
-// triangles (about three tests per ray) come from global memory.  Same walk and same bookkeeping as k_trace_pair
-// (near child at once, far child's `tnear < maxt` finished at its pop, exact re-test through the node array when
-// the stored bits of tnear cannot decide); todo entries are 4 bytes: 13-bit reference + the top 19 bits of tnear
-// (closest) or the count of missed far children under the entry (any hit).
-typedef PT_AS_LDS const unsigned char *lds_bytes_t;
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));      // (HIP's uint4 class cannot be read through an LDS pointer)
-typedef PT_AS_LDS const u32x4_t *lds_u4_t;
-typedef PT_AS_LDS const double *lds_f64_t;
-typedef PT_AS_LDS unsigned *lds_u32_t;
-
-struct LdsStack {
-    lds_u32_t lds;       // + thread
-    unsigned *spill;     // + grid thread (levels >= L)
-    long spill_stride;
-    int L;
-};
-template <int BLOCK>
-__device__ __forceinline__ void lds_push(const LdsStack &st, int level, unsigned e) {
-    if (level < st.L) st.lds[level * BLOCK] = e;
-    else st.spill[(long)(level - st.L) * st.spill_stride] = e;
-}
-template <int BLOCK>
-__device__ __forceinline__ unsigned lds_pop(const LdsStack &st, int level) {
-    if (level < st.L) return st.lds[level * BLOCK];
-    return st.spill[(long)(level - st.L) * st.spill_stride];
-}
-
-template <bool ANY, int BLOCK>
-__device__ __forceinline__ int traverse_lds_loop(const DScene &sc, lds_bytes_t img, Ray &r, const SlabRay &sv,
-                                                 const LdsStack &stack, double &b1o, double &b2o, unsigned &nvis,
-                                                 unsigned &ntri) {
-    int result = ANY ? 0 : -1;
-    const lds_u4_t rec = reinterpret_cast<lds_u4_t>(img + sizeof(LdsTreeHead));
-    const lds_f64_t dx = reinterpret_cast<lds_f64_t>(img + sc.lds_tree.off_dx);
-    const lds_f64_t dy = reinterpret_cast<lds_f64_t>(img + sc.lds_tree.off_dy);
-    const lds_f64_t dz = reinterpret_cast<lds_f64_t>(img + sc.lds_tree.off_dz);
-    unsigned ref;
-    {   // the root: a visit like any other
-        const lds_f64_t rb = reinterpret_cast<lds_f64_t>(img);
-        const double2 n0 = make_double2(rb[0], rb[1]), n1 = make_double2(rb[2], rb[3]), n2 = make_double2(rb[4], rb[5]);
-        nvis++;
-        if (!slab_hit<true>(n0, n1, n2, r, sv)) return result;
-        ref = (unsigned)reinterpret_cast<PT_AS_LDS const int *>(img)[12];       // LdsTreeHead::root_ref
-    }
-    int todo = 0;
-    unsigned pend = 0;
-    const unsigned POP = 0xFFFFFFFFu;
-    for (;;) {
-        unsigned next;
-        if (ref & PT_LDS_REF_LEAF) {
-            const int first = (int)(ref & 0xFFFu);
-            int n = 1;
-            for (int i = 0; i < n; i++) {
-                const double2 *q = reinterpret_cast<const double2 *>(sc.tris + first + i);
-                const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
-                if (i == 0) n = __double2loint(a4.y);          // GTri::leaf_nprim
-                double t, b1, b2;
-                ntri++;
-                if (tri_math(a0, a1, a2, a3, a4, r, t, b1, b2)) {
-                    if (ANY) return 1;
-                    result = first + i;
-                    b1o = b1; b2o = b2;
-                    r.maxt = t;
-                }
-            }
-            next = POP;
-        } else {
-            const u32x4_t q0 = rec[2 * ref], q1 = rec[2 * ref + 1];
-            // planes of both children from the dictionaries (LPair::b0, b1: min x y z, max x y z)
-            const double c0nx = dx[q0.x & 0xFFFFu], c0ny = dy[q0.x >> 16], c0nz = dz[q0.y & 0xFFFFu];
-            const double c0xx = dx[q0.y >> 16], c0xy = dy[q0.z & 0xFFFFu], c0xz = dz[q0.z >> 16];
-            const double c1nx = dx[q0.w & 0xFFFFu], c1ny = dy[q0.w >> 16], c1nz = dz[q1.x & 0xFFFFu];
-            const double c1xx = dx[q1.x >> 16], c1xy = dy[q1.y & 0xFFFFu], c1xz = dz[q1.y >> 16];
-            const unsigned meta = q1.z;
-            const double ax0 = (c0nx - r.o.x) * sv.invx, ax1 = (c0xx - r.o.x) * sv.invx;
-            const double ay0 = (c0ny - r.o.y) * sv.invy, ay1 = (c0xy - r.o.y) * sv.invy;
-            const double az0 = (c0nz - r.o.z) * sv.invz, az1 = (c0xz - r.o.z) * sv.invz;
-            const double bx0 = (c1nx - r.o.x) * sv.invx, bx1 = (c1xx - r.o.x) * sv.invx;
-            const double by0 = (c1ny - r.o.y) * sv.invy, by1 = (c1xy - r.o.y) * sv.invy;
-            const double bz0 = (c1nz - r.o.z) * sv.invz, bz1 = (c1xz - r.o.z) * sv.invz;
-            const double tn0 = fmax(fmax(fmin(ax0, ax1), fmin(ay0, ay1)), fmin(az0, az1));
-            const double tf0 = fmin(fmin(fmax(ax0, ax1), fmax(ay0, ay1)), fmax(az0, az1));
-            const double tn1 = fmax(fmax(fmin(bx0, bx1), fmin(by0, by1)), fmin(bz0, bz1));
-            const double tf1 = fmin(fmin(fmax(bx0, bx1), fmax(by0, by1)), fmax(bz0, bz1));
-            const bool ok0 = (tn0 <= tf0) && (tn0 < r.maxt) && (tf0 > r.mint);
-            const bool ok1 = (tn1 <= tf1) && (tn1 < r.maxt) && (tf1 > r.mint);
-            const bool neg = (sv.negmask >> (meta >> 26)) & 1;
-            const bool okN = neg ? ok1 : ok0, okF = neg ? ok0 : ok1;
-            const unsigned r0 = meta & PT_LDS_REF_MASK, r1 = (meta >> 13) & PT_LDS_REF_MASK;
-            const unsigned refN = neg ? r1 : r0, refF = neg ? r0 : r1;
-            nvis++;
-            if (okN) {
-                if (okF) {
-                    const unsigned aux = ANY ? (pend << 13) : ((unsigned)__double2hiint(neg ? tn0 : tn1) & 0xFFFFE000u);
-                    lds_push<BLOCK>(stack, todo, aux | refF);
-                    todo++;
-                    pend = 0;
-                } else if (ANY) pend++;
-                else nvis++;
-                next = refN;
-            } else {
-                nvis++;
-                next = okF ? refF : POP;
-            }
-        }
-        if (next == POP) {
-            if (ANY) {
-                nvis += pend;
-                if (todo == 0) break;
-                todo--;
-                const unsigned e = lds_pop<BLOCK>(stack, todo);
-                nvis++;
-                pend = e >> 13;
-                next = e & PT_LDS_REF_MASK;
-            } else {
-                for (;;) {
-                    if (todo == 0) break;
-                    todo--;
-                    const unsigned e = lds_pop<BLOCK>(stack, todo);
-                    nvis++;
-                    const int hw = (int)(e & 0xFFFFE000u);
-                    const double lo = __hiloint2double(hw, 0), hi = __hiloint2double(hw | 0x1FFF, (int)0xFFFFFFFF);
-                    const bool sure_hit = (r.maxt > lo) && (r.maxt > hi);
-                    const bool sure_miss = (r.maxt <= lo) && (r.maxt <= hi);
-                    bool hit = sure_hit;
-                    if (!sure_hit && !sure_miss) {
-                        const unsigned rr = e & PT_LDS_REF_MASK;
-                        const int gref = (rr & PT_LDS_REF_LEAF) ? ~(int)(rr & 0xFFFu) : (int)rr;
-                        hit = exact_tnear_lt_maxt(sc, gref, r, sv.invx, sv.invy, sv.invz);
-                    }
-                    if (hit) { next = e & PT_LDS_REF_MASK; break; }
-                }
-                if (next == POP) break;
-            }
-        }
-        ref = next;
-    }
-    return result;
-}
-
-template <bool ANY>
-__global__ __launch_bounds__(PT_LDS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trace_lds(DScene sc, const double *__restrict__ rays, long stride,
-                                                            const int *__restrict__ seg_counts, long seg, int n_val,
-                                                            int *__restrict__ out_prim, double *__restrict__ out_t,
-                                                            double *__restrict__ out_b1, double *__restrict__ out_b2,
-                                                            ShadowResolve rs, unsigned long long *counters,
-                                                            unsigned *__restrict__ spill, int lds_levels) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(sc.lds_tree.blob);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_mem);
-        for (int k = threadIdx.x; k < sc.lds_tree.bytes / 16; k += PT_LDS_BLOCK) dst[k] = src[k];
-    }
-    __syncthreads();
-    const lds_bytes_t img = (lds_bytes_t)s_mem;
-    LdsStack stack;
-    stack.lds = (lds_u32_t)(s_mem + sc.lds_tree.bytes) + threadIdx.x;
-    stack.spill = spill + ((long)blockIdx.x * PT_LDS_BLOCK + threadIdx.x);
-    stack.spill_stride = (long)gridDim.x * PT_LDS_BLOCK;
-    stack.L = lds_levels;
-    unsigned nvis = 0, ntri = 0;
-    const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
-    const unsigned nray = for_each_ray<PT_LDS_BLOCK>(seg_counts, seg, n_val, [&](long i) {
-        Ray r = load_ray(rays, stride, i);
-        double b1 = 0., b2 = 0.;
-        int res = ANY ? 0 : -1;
-        if (sc.n_nodes > 0) {
-            const SlabRay sv = slab_ray(sc, r);
-            if (sv.fast) res = traverse_lds_loop<ANY, PT_LDS_BLOCK>(sc, img, r, sv, stack, b1, b2, nvis, ntri);
-            else   // the literal walk: node array, its whole stack in the spill area (one int per level, 8-byte pitch)
-                res = traverse_loop<ANY, false>(sc, r, sv, reinterpret_cast<int *>(stack.spill), b1, b2, nvis, ntri,
-                                                stack.spill_stride);
-        }
-        store_result<ANY>(out, i, res, r, b1, b2);
-    });
-    if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
-}
-
-hipError_t pt_launch_trace_lds(bool any, int levels, void *spill, int grid, hipStream_t stream, const DScene &sc,
-                               const double *rays, long stride, const int *seg_counts, long seg, int n_val, int *out_prim,
-                               double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
-                               unsigned long long *counters) {
-    static bool attr_set[PT_MAX_DEVICES][2];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
-    if (!attr_set[dev][any ? 1 : 0]) {
-        hipError_t e = any ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set[dev][any ? 1 : 0] = true;
-    }
-    // todo levels in LDS: what is left beside the image (4-byte entries), at most what the tree needs
-    const long room = (long)160 * 1024 - 1024 - sc.lds_tree.bytes;
-    int L = (int)std::min<long>(levels, room / ((long)PT_LDS_BLOCK * 4));
-    if (L < 1) return hipErrorInvalidValue;
-    const size_t lds = (size_t)sc.lds_tree.bytes + (size_t)L * PT_LDS_BLOCK * 4;
-    if (any)
-        hipLaunchKernelGGL((k_trace_lds<true>), dim3(grid), dim3(PT_LDS_BLOCK), lds, stream, sc, rays, stride, seg_counts,
-                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (unsigned *)spill, L);
-    else
-        hipLaunchKernelGGL((k_trace_lds<false>), dim3(grid), dim3(PT_LDS_BLOCK), lds, stream, sc, rays, stride, seg_counts,
-                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (unsigned *)spill, L);
     return hipGetLastError();
 }
 

@@ -137,7 +137,7 @@ def test_axis_parallel_rays_on_box_planes(torch_cuda, ctx, golden_dir):
     assert (gs.node_visits, gs.tri_tests) == (os_.node_visits, os_.tri_tests)
 
 
-@pytest.mark.parametrize('knob', [('PT_TRACE_TOP', '1'), ('PT_TRACE_META', '2'), ('PT_TRACE_META', '0'), ('PT_TRACE_PAIR', '3'), ('PT_TRACE_LDS', '3')])
+@pytest.mark.parametrize('knob', [('PT_TRACE_TOP', '1'), ('PT_TRACE_META', '2'), ('PT_TRACE_META', '0'), ('PT_TRACE_PAIR', '3')])
 def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head, knob):
     """k_trace_top (first breadth-first nodes staged in LDS; default only for trees beyond the L2), k_trace_meta
     (child/primitive words of all nodes in LDS; default for closest-hit launches on small trees), k_trace_pair (the
