@@ -12,8 +12,10 @@ closest/any hit → shading/light sampling → film splat (+ RCCL reduce of the 
 → film resolve.  Inputs (scene, descriptors) are resident in HBM before the timed region.
 
 Multi-GPU (default, "strong" scaling — the metric's job is the FIXED 1024^2 x 64 spp render at 1/2/4/8 GPUs):
-replicated scene, same seed on every rank, rank r renders `renderer.shard_tile(sampler, r, N, 'samples')` = sample
-indices [64 r / N, 64 (r+1) / N) of every pixel (the reference's own decomposition hook is
+replicated scene, same seed on every rank, rank r renders `renderer.shard_tile(sampler, r, N, 'interleaved')` = the
+rows r, r + N, r + 2N, … with all 64 samples of their pixels (balanced like a sample-index split, but every pixel
+stays on one rank: coherent waves, one film-footprint pass; `--shard-mode samples|rows` for the other splits; the
+reference's own decomposition hook is
 Sampler.compute_subwindow, sampler/sampler/__init__.py:87-111, unused there: renderer.py:97-109); the only
 collective is one reduce(sum) of the f64 film accumulators to rank 0.  Sample streams are functions of (pixel,
 sample index, seed), so the N-rank film equals the 1-rank film up to the order of the additions: rank 0 renders the
@@ -55,7 +57,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--weak', action='store_true', help='N > 1: per-rank sample streams (seed = rank), 64 spp per rank')
     ap.add_argument('--shard-of', default='', help='one GPU: comma list of K; time shard 0 of K for each (scaling proxy)')
-    ap.add_argument('--shard-mode', choices=['samples', 'rows'], default='samples')
+    ap.add_argument('--shard-mode', choices=['interleaved', 'samples', 'rows'], default='interleaved')
     ap.add_argument('--workload', choices=['head', 'c2', 'c4', 'c5'], default='head',
                     help='head = BASELINE.json configs[2] (the metric; default).  Secondary, for DESIGN.md only: '
                          'c2 = configs[1] head_loop 512^2 x 16 spp Direct; c4 = configs[3] 10^6-triangle soup '
@@ -237,15 +239,17 @@ def main():
             tk = shard_tile(smp, 0, K, args.shard_mode)
             step(A.pt_stats(), tk)
             torch.cuda.synchronize()
+            stk = A.pt_stats()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                step(A.pt_stats(), tk)
+                step(stk, tk)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t1) / args.steps * 1e3
             if K == 1:
                 t_full = ms
-            proxy[str(K)] = {'ms_per_step': ms, 'spp_per_shard': tk.s1 - tk.s0, 'rows_per_shard': tk.y1 - tk.y0,
-                             'predicted_efficiency': t_full / (K * ms)}
+            proxy[str(K)] = {'ms_per_step': ms, 'spp_per_shard': tk.s1 - tk.s0, 'rows_per_shard': tk.rows(),
+                             'predicted_efficiency': t_full / (K * ms),
+                             'stage_ms_per_step': {k: v / args.steps for k, v in stk.timing().items()}}
         # the reduce itself cannot be timed on one GPU: its on-device half (acc += other, 32 MiB f64) can
         other = torch.ones_like(acc)
         torch.cuda.synchronize()
@@ -318,7 +322,7 @@ def main():
                        'parallelism': ('single GPU' if world == 1 else
                                        'replicated scene, per-rank sample streams (seed = rank), RCCL film reduce' if args.weak
                                        else 'replicated scene, fixed job sharded by %s (shard_tile), one RCCL film reduce'
-                                       % ('sample index' if args.shard_mode == 'samples' else 'row bands')),
+                                       % {'samples': 'sample index', 'rows': 'row bands', 'interleaved': 'interleaved rows'}[args.shard_mode]),
                        'image_checksum': float(rgb.sum().item())},
             'roofline': roof,
         }

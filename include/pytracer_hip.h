@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 10
+#define PT_ABI_VERSION 11
 
 typedef enum {
     PT_OK = 0,
@@ -191,8 +191,14 @@ typedef struct {
     int32_t _pad;
 } pt_integrator_desc;
 
-/* work shard: pixels [x0,x1)×[y0,y1) of the sampler window, sample indices [s0,s1) */
-typedef struct { int32_t x0, x1, y0, y1, s0, s1; } pt_tile;
+/* work shard: pixels [x0,x1)×[y0,y1) of the sampler window, sample indices [s0,s1).
+ * y_step > 1 keeps only the rows y0 + y_phase + k*y_step (k = 0, 1, …) below y1: the interleaved-rows shard
+ * of a multi-GPU render (rank r of N: y_step = N, y_phase = r) — every rank gets rows from all over the image
+ * (balanced load) and every pixel keeps all its samples on one rank (coherent waves, one film footprint pass).
+ * y_step = 0 or 1: every row.  Samples are numbered in tile order: kept rows top to bottom, x, then sample index
+ * (the order of sample_L).  The reference's decomposition hook is Sampler.compute_subwindow
+ * (sampler/sampler/__init__.py:87-111), unused there (renderer/renderer.py:97-109,135). */
+typedef struct { int32_t x0, x1, y0, y1, s0, s1; int32_t y_step, y_phase; } pt_tile;
 
 typedef struct {
     uint64_t camera_samples;

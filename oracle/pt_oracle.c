@@ -1297,7 +1297,8 @@ int pto_render(void *scene, const pt_camera *cam, const pt_film_desc *film, cons
     octx c; c.s = s; c.st = stats;
     double rowbuf[512];
     int64_t out_i = 0;
-    for (int py = tile->y0; py < tile->y1; py++)
+    const int y_step = tile->y_step > 1 ? tile->y_step : 1;      /* interleaved rows (include/pytracer_hip.h pt_tile) */
+    for (int py = tile->y0 + (y_step > 1 ? tile->y_phase : 0); py < tile->y1; py += y_step)
         for (int px = tile->x0; px < tile->x1; px++)
             for (int si = tile->s0; si < tile->s1; si++, out_i++) {
                 uint32_t sid = (uint32_t)((((int64_t)(py - sp->y_start) * W + (px - sp->x_start)) * spp) + si);

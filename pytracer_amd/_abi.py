@@ -1,7 +1,7 @@
 """ctypes mirror of include/pytracer_hip.h (struct layouts and enums only)."""
 import ctypes as C
 
-PT_ABI_VERSION = 10
+PT_ABI_VERSION = 11
 PT_INTERSECT_STATIC_MAX_RAYS = 0x40000000
 PT_MAX_LOBES = 5
 
@@ -71,7 +71,15 @@ class pt_integrator_desc(C.Structure):
 
 class pt_tile(C.Structure):
     _fields_ = [('x0', C.c_int32), ('x1', C.c_int32), ('y0', C.c_int32), ('y1', C.c_int32),
-                ('s0', C.c_int32), ('s1', C.c_int32)]
+                ('s0', C.c_int32), ('s1', C.c_int32), ('y_step', C.c_int32), ('y_phase', C.c_int32)]
+
+    def rows(self):
+        """number of rows the tile keeps (include/pytracer_hip.h: y_step / y_phase)"""
+        st = max(int(self.y_step), 1)
+        return max(0, (self.y1 - self.y0 - self.y_phase + st - 1) // st)
+
+    def n_samples(self):
+        return self.rows() * (self.x1 - self.x0) * (self.s1 - self.s0)
 
 
 class pt_stats(C.Structure):

@@ -152,7 +152,7 @@ class Context(object):
             assert table.shape[0] == window, (table.shape, window)
             dims = table.shape[1]
         if sample_L is not None:
-            n = (tile.x1 - tile.x0) * (tile.y1 - tile.y0) * (tile.s1 - tile.s0)
+            n = tile.n_samples()
             assert sample_L.is_cuda and sample_L.dtype == torch.float64 and sample_L.is_contiguous()
             assert tuple(sample_L.shape) == (n, 3)
         self._check(lib().pt_render(self._h, C.byref(cam), C.byref(film), C.byref(sampler), C.byref(integ),

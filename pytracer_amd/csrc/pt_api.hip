@@ -38,13 +38,16 @@ struct pt_ctx {
     void *ws;
     size_t ws_bytes;
     Queue q[2];
-    ShadowQueue sh;
-    PathState st;
+    ShadowQueue sh[2];       // double-buffered: the any-hit trace of level k runs on `aux` beside level k+1's closest-hit
+    PathState st;            // trace and shading, which fills the other buffer
+    hipStream_t aux;         // second stream of a render (created with the context)
+    hipEvent_t ev_shade[2], ev_any[2];   // shade(k) done -> aux may trace sh[k&1]; that trace done -> sh[k&1] may be refilled
+    int overlap;             // PT_OVERLAP=0: everything on the caller's stream
     int use_top;             // stage the top of the tree in LDS (k_trace_top): PT_TRACE_TOP=0 never, 1 always,
                              // unset = for trees beyond the L2 (>= 2^18 nodes = 16 MB).  Measured:
                              // head mesh 5.5 k nodes -5 %, head_loop 352 k nodes +5 %, 10^6-triangle soup +19 %
     int *hit_idx;            // [cap] hit list of the current closest-hit trace (HitList::idx)
-    int *d_counts;           // [4][PT_SEG]: region fill counters of q0, q1, the shadow queue and the hit list
+    int *d_counts;           // [5][PT_SEG]: region fill counters of q0, q1, shadow queue 0, the hit list, shadow queue 1
     int trace_occ[2];        // resident blocks/CU of the closest / any trace kernels (0 = not queried)
     int pair_occ[2];         // the same for k_trace_pair
     int pair_levels;         // todo levels the tree needs; the first pair_lds_levels of them live in LDS (PT_PAIR_LDS_LEVELS)
@@ -151,7 +154,8 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    CREATE_CHK(hipMalloc((void **)&c->d_counts, 4 * PT_CNT_BLOCK * sizeof(int)));
+    // region fill counters of q0, q1, shadow queue 0, the hit list, shadow queue 1
+    CREATE_CHK(hipMalloc((void **)&c->d_counts, 5 * PT_CNT_BLOCK * sizeof(int)));
     c->use_top = -1;
     if (const char *e = getenv("PT_TRACE_TOP")) c->use_top = atoi(e);
     c->use_meta = 1;
@@ -161,6 +165,13 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
     // + 4 words behind the census shards: the channel maxima of pt_film_to_u8
     CREATE_CHK(hipMalloc((void **)&c->d_counters, (PT_CNT_SHARDS * CNT_COUNT + 4) * sizeof(unsigned long long)));
+    c->overlap = 1;
+    if (const char *e = getenv("PT_OVERLAP")) c->overlap = atoi(e);
+    CREATE_CHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+        CREATE_CHK(hipEventCreateWithFlags(&c->ev_shade[k], hipEventDisableTiming));
+        CREATE_CHK(hipEventCreateWithFlags(&c->ev_any[k], hipEventDisableTiming));
+    }
     c->ev = new std::vector<hipEvent_t>();
     c->ev_stage = new std::vector<int>();
     *out = c;
@@ -231,6 +242,11 @@ extern "C" int pt_ctx_destroy(pt_ctx *c) {
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_rc) (void)hipFree(c->d_rc);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+    for (int k = 0; k < 2; k++) {
+        if (c->ev_shade[k]) (void)hipEventDestroy(c->ev_shade[k]);
+        if (c->ev_any[k]) (void)hipEventDestroy(c->ev_any[k]);
+    }
     if (c->ev) { for (hipEvent_t e : *c->ev) (void)hipEventDestroy(e); delete c->ev; }
     delete c->ev_stage;
     free(c);
@@ -810,8 +826,12 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv, int gshift) {
         off_q[k][4] = need(cap * sizeof(double));
         off_q[k][5] = need(cap * sizeof(double));
     }
-    size_t off_sr = need(8 * sh_cap * sizeof(double)), off_sc = need(3 * sh_cap * sizeof(double));
-    size_t off_ss = need(sh_cap * sizeof(int));
+    size_t off_sr[2], off_sc[2], off_ss[2];
+    for (int k = 0; k < 2; k++) {
+        off_sr[k] = need(8 * sh_cap * sizeof(double));
+        off_sc[k] = need(3 * sh_cap * sizeof(double));
+        off_ss[k] = need(sh_cap * sizeof(int));
+    }
     size_t off_T = need(3 * cap * sizeof(double)), off_L = need(3 * cap * sizeof(double));
     size_t off_img = need(2 * cap * sizeof(double));
     size_t off_hit = need(cap * sizeof(int));
@@ -824,8 +844,11 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv, int gshift) {
         q.t = (double *)(b + off_q[k][3]); q.b1 = (double *)(b + off_q[k][4]); q.b2 = (double *)(b + off_q[k][5]);
         q.count = c->d_counts + k * PT_CNT_BLOCK;
     }
-    c->sh.rays = (double *)(b + off_sr); c->sh.c = (double *)(b + off_sc); c->sh.slot = (int *)(b + off_ss);
-    c->sh.stride = sh_cap; c->sh.seg = seg * spv; c->sh.count = c->d_counts + 2 * PT_CNT_BLOCK;
+    for (int k = 0; k < 2; k++) {
+        ShadowQueue &sh = c->sh[k];
+        sh.rays = (double *)(b + off_sr[k]); sh.c = (double *)(b + off_sc[k]); sh.slot = (int *)(b + off_ss[k]);
+        sh.stride = sh_cap; sh.seg = seg * spv; sh.count = c->d_counts + (k ? 4 : 2) * PT_CNT_BLOCK;
+    }
     c->st.T = (double *)(b + off_T); c->st.L = (double *)(b + off_L); c->st.img = (double *)(b + off_img);
     c->st.stride = cap;
     c->hit_idx = (int *)(b + off_hit);
@@ -879,6 +902,9 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     if (tile->x0 < sp->x_start || tile->x1 > sp->x_end || tile->y0 < sp->y_start || tile->y1 > sp->y_end ||
         tile->x1 < tile->x0 || tile->y1 < tile->y0 || tile->s0 < 0 || tile->s1 > spp || tile->s1 < tile->s0)
         return fail(c, PT_ERR_ARG, "tile outside the sampler window");
+    if (tile->y_step < 0 || tile->y_phase < 0 || (tile->y_step > 1 ? tile->y_phase >= tile->y_step : tile->y_phase != 0))
+        return fail(c, PT_ERR_ARG, "tile row interleave: need 0 <= y_phase < y_step (y_step %d, y_phase %d)", tile->y_step,
+                    tile->y_phase);
     if (film->x_cnt < 1 || film->y_cnt < 1 || !(film->xw > 0.) || !(film->yw > 0.)) return fail(c, PT_ERR_ARG, "film");
     const long window = (long)(sp->x_end - sp->x_start) * (sp->y_end - sp->y_start) * spp;
     if (window > 0xFFFFFFFFl) return fail(c, PT_ERR_CAPACITY, "more than 2^32 samples in the sampler window");
@@ -889,7 +915,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     h.table = sample_table;
     if (sample_table && table_dims != h.lay.dims)
         return fail(c, PT_ERR_ARG, "sample table has %d dims, this scene/integrator needs %d", table_dims, h.lay.dims);
-    const long total = (long)(tile->x1 - tile->x0) * (tile->y1 - tile->y0) * (tile->s1 - tile->s0);
+    const long total = (long)(tile->x1 - tile->x0) * pt_tile_rows(*tile) * (tile->s1 - tile->s0);
     if (total == 0) return PT_OK;
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard dg(c->device);
@@ -903,7 +929,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t per_path = 8 * 8 * 2 + 4 * 2 * 2 + 8 * 3 * 2 + (8 * 11 + 4) * (size_t)std::max(1, ig->kind == PT_INTEG_DIRECT ? c->shadow_per_vertex_direct : (ig->kind == PT_INTEG_WHITTED ? c->sc.n_lights : 1)) + 8 * 8;
+            const size_t per_path = 8 * 8 * 2 + 4 * 2 * 2 + 8 * 3 * 2 + 2 * (8 * 11 + 4) * (size_t)std::max(1, ig->kind == PT_INTEG_DIRECT ? c->shadow_per_vertex_direct : (ig->kind == PT_INTEG_WHITTED ? c->sc.n_lights : 1)) + 8 * 8;
             const size_t budget = (free_b + c->ws_bytes) / 2;     // leave half of what is free to the caller
             const long fit = (long)(budget / per_path);
             if (fit < batch) batch = std::max(fit, 1l << 16);
@@ -961,31 +987,54 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
                                    c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
         }
         int cur = 0;
+        // The any-hit (shadow) trace of level k depends only on shade(k); level k+1's closest-hit trace, hit list and
+        // shading do not depend on it (its only output is atomic adds into L).  With PT_OVERLAP (default) it runs on
+        // the context's second stream beside them: the sparse deep-bounce launches no longer leave the machine idle
+        // in their tails.  Shadow queues alternate, so shade(k+2) waits for trace_any(k).
+        const bool ovl = c->overlap != 0;
+        bool any_pending[2] = {false, false};
         for (int level = 0; level < levels; level++) {
             Queue &qin = c->q[cur], &qout = c->q[cur ^ 1];
+            const int sb = ovl ? (level & 1) : 0;
+            ShadowQueue &sh = c->sh[sb];
+            if (ovl && any_pending[sb]) {
+                HIPCHK(c, hipStreamWaitEvent(stream, c->ev_any[sb], 0));
+                any_pending[sb] = false;
+            }
             HIPCHK(c, hipMemsetAsync(qout.count, 0, PT_CNT_BLOCK * sizeof(int), stream));
-            HIPCHK(c, hipMemsetAsync(c->sh.count, 0, PT_CNT_BLOCK * sizeof(int), stream));
+            HIPCHK(c, hipMemsetAsync(sh.count, 0, PT_CNT_BLOCK * sizeof(int), stream));
             {
                 StageTimer tm(c, stream, STAGE_SHADE);
                 HIPCHK(c, hipMemsetAsync(c->d_counts + 3 * PT_CNT_BLOCK, 0, PT_CNT_BLOCK * sizeof(int), stream));
                 HIPCHK(c, pt_launch_list_hits(gs * 2, stream, qin, hit_list(level)));
                 HIPCHK(c, pt_launch_shade(ig->kind, gs, stream, c->sc, c->d_rc, base, level, qin, hit_list(level), qout,
-                                          c->sh, c->st));
+                                          sh, c->st));
             }
-            ShadowResolve rs = {c->sh.c, c->sh.stride, c->sh.slot, c->st.L, c->st.stride};
+            ShadowResolve rs = {sh.c, sh.stride, sh.slot, c->st.L, c->st.stride};
+            hipStream_t any_stream = stream;
+            if (ovl) {
+                HIPCHK(c, hipEventRecord(c->ev_shade[sb], stream));
+                HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_shade[sb], 0));
+                any_stream = c->aux;
+            }
             {
-                StageTimer tm(c, stream, STAGE_TRACE_ANY);
-                HIPCHK(c, launch_trace(c, true, (long)nb * spv, stream, c->sh.rays, c->sh.stride, c->sh.count, c->sh.seg,
+                StageTimer tm(c, any_stream, STAGE_TRACE_ANY);
+                HIPCHK(c, launch_trace(c, true, (long)nb * spv, any_stream, sh.rays, sh.stride, sh.count, sh.seg,
                                        0, nullptr, nullptr, nullptr, nullptr, rs, cnt));
             }
+            if (ovl) {
+                HIPCHK(c, hipEventRecord(c->ev_any[sb], c->aux));
+                any_pending[sb] = true;
+            }
             if (getenv("PT_DEBUG_LEVELS") && base == 0) {   // debugging aid: queue sizes per level (syncs)
-                std::vector<int> h(4 * PT_CNT_BLOCK);
-                long tot[4] = {0, 0, 0, 0};
+                std::vector<int> h(5 * PT_CNT_BLOCK);
+                long tot[5] = {0, 0, 0, 0, 0};
+                (void)hipStreamSynchronize(c->aux);
                 (void)hipMemcpyAsync(h.data(), c->d_counts, h.size() * sizeof(int), hipMemcpyDeviceToHost, stream);
                 (void)hipStreamSynchronize(stream);
-                for (int k = 0; k < 4 * PT_CNT_BLOCK; k += PT_CNT_STRIDE) tot[k / PT_CNT_BLOCK] += h[k];
+                for (int k = 0; k < 5 * PT_CNT_BLOCK; k += PT_CNT_STRIDE) tot[k / PT_CNT_BLOCK] += h[k];
                 fprintf(stderr, "[pt] level %d: in %ld (hits %ld), continuation %ld, shadow %ld\n", level, tot[cur], tot[3],
-                        tot[cur ^ 1], tot[2]);
+                        tot[cur ^ 1], tot[sb ? 4 : 2]);
             }
             if (level + 1 < levels) {
                 StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
@@ -994,6 +1043,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
                 cur ^= 1;
             }
         }
+        for (int k = 0; k < 2; k++)      // the film needs every shadow contribution
+            if (any_pending[k]) HIPCHK(c, hipStreamWaitEvent(stream, c->ev_any[k], 0));
         {
             StageTimer tm(c, stream, STAGE_SPLAT);
             HIPCHK(c, pt_launch_splat(stream, c->d_rc, *tile, *film, base, nb, c->st, film_accum, sample_L, cnt));

@@ -23,6 +23,16 @@ enum {
     CNT_COUNT
 };
 
+// rows of a tile (include/pytracer_hip.h pt_tile: y_step / y_phase interleave)
+__host__ __device__ inline int pt_tile_rows(const pt_tile &t) {
+    const int st = t.y_step > 1 ? t.y_step : 1, ph = t.y_step > 1 ? t.y_phase : 0;
+    const int span = t.y1 - t.y0 - ph;
+    return span > 0 ? (span + st - 1) / st : 0;
+}
+__host__ __device__ inline int pt_tile_row_y(const pt_tile &t, int row) {
+    return t.y_step > 1 ? t.y0 + t.y_phase + row * t.y_step : t.y0 + row;
+}
+
 // Segmented queues.  A render queue of capacity `stride` is PT_SEG regions of `seg` entries
 // (stride = PT_SEG * seg), each with its own fill counter; entry k of region r is element
 // r*seg + k of every array.  Region r is a private lane through the pipeline: the waves with

@@ -779,7 +779,7 @@ __device__ __forceinline__ void tile_decode(const RenderConst &rc, long out_i, i
     const uint32_t pix = o / ns;
     si = rc.tile.s0 + (int)(o - pix * ns);
     const uint32_t row = pix / tw;
-    py = rc.tile.y0 + (int)row;
+    py = pt_tile_row_y(rc.tile, (int)row);
     px = rc.tile.x0 + (int)(pix - row * tw);
     const int spp = rc.sp.xs * rc.sp.ys, W = rc.sp.x_end - rc.sp.x_start;
     sid = (uint32_t)((((long)(py - rc.sp.y_start) * W + (px - rc.sp.x_start)) * spp) + si);
@@ -1202,9 +1202,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_list_hits(Queue q, HitList hl) {
         if (live && prim < 0 && hl.add_escape) {
             const int slot = q.slot[first + k];
             const long P = hl.pstride;
-            hl.L[slot] += hl.T[slot] * hl.le[0];
-            hl.L[P + slot] += hl.T[P + slot] * hl.le[1];
-            hl.L[2 * P + slot] += hl.T[2 * P + slot] * hl.le[2];
+            // atomic: the previous level's shadow trace may be adding to the same L[slot] on the other stream
+            unsafeAtomicAdd(hl.L + slot, hl.T[slot] * hl.le[0]);
+            unsafeAtomicAdd(hl.L + P + slot, hl.T[P + slot] * hl.le[1]);
+            unsafeAtomicAdd(hl.L + 2 * P + slot, hl.T[2 * P + slot] * hl.le[2]);
         }
         const int pos = wave_append(prim >= 0, hl.count + region * PT_CNT_STRIDE);
         if (pos >= 0) hl.idx[first + pos] = k;
@@ -1287,7 +1288,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_splat(const RenderConst *__restric
     const int nchunks = (tw + SPLAT_PX - 1) / SPLAT_PX;
     const int row = row_first + (int)(blockIdx.x / nchunks);          // row inside the tile
     const int cx0 = (int)(blockIdx.x % nchunks) * SPLAT_PX;           // first strip pixel inside the tile
-    const int py = rc.tile.y0 + row;
+    const int py = pt_tile_row_y(rc.tile, row);
     const int tw_l = SPLAT_PX + 2 * hx, th_l = 2 * hy + 1;
     const int lx0 = rc.tile.x0 + cx0 - hx, ly0 = py - hy;             // film coords of LDS tile origin
     const int plane = tw_l * th_l;

@@ -601,7 +601,10 @@ def integrator_desc_from_object(integ, pretest=False):
     raise NotImplementedError('integrator %s is outside the supported hot path' % nm)
 
 
-def tile_desc(x0, x1, y0, y1, s0, s1):
+def tile_desc(x0, x1, y0, y1, s0, s1, y_step=1, y_phase=0):
     t = A.pt_tile()
     t.x0, t.x1, t.y0, t.y1, t.s0, t.s1 = int(x0), int(x1), int(y0), int(y1), int(s0), int(s1)
+    t.y_step, t.y_phase = int(y_step), int(y_phase)
+    if t.y_step < 0 or t.y_phase < 0 or (t.y_phase and t.y_phase >= max(t.y_step, 1)):
+        raise ValueError('tile row interleave: need 0 <= y_phase < y_step')
     return t

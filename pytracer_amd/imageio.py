@@ -117,6 +117,6 @@ def sample_chunks(tile, every, start=None):
         raise ValueError('checkpoint_every must be >= 1')
     while s < tile.s1:
         e = min(s + every, tile.s1)
-        yield tile_desc(tile.x0, tile.x1, tile.y0, tile.y1, s, e)
+        yield tile_desc(tile.x0, tile.x1, tile.y0, tile.y1, s, e, tile.y_step, tile.y_phase)
         s = e
 

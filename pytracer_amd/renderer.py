@@ -21,16 +21,27 @@ from . import flatten as F
 from . import imageio as IO
 
 
-def shard_tile(sampler, rank, world, mode='samples'):
+def shard_tile(sampler, rank, world, mode='interleaved'):
     """The work shard of `rank` out of `world` (include/pytracer_hip.h pt_tile).
 
-    mode 'samples': all pixels, sample indices [s0, s1) — perfect load balance (every rank sees the
-    whole image).  mode 'rows': a band of rows, all sample indices — better ray coherence; the film
-    footprint of a sample crosses band borders, which is why every rank keeps a FULL film
-    accumulator and the shards are summed.  Falls back to rows when spp < world.
+    mode 'interleaved' (default): rows rank, rank + world, rank + 2 world, … with all their samples — every rank
+    sees rows from all over the image (balanced like a sample split) and every pixel keeps its samples on one rank
+    (waves stay coherent, the per-pixel film pass is not repeated on every rank).  Measured on one MI355X as shard 0
+    of 8 of the 1024^2 x 64 spp head-mesh render: 'samples' 14.7 ms (splat 1.9 ms instead of
+    0.4: its per-pixel cost does not shrink with the sample count), contiguous 'rows' bands are unbalanced (the top
+    band 6.4 ms, the head's bands far more).
+    mode 'samples': all pixels, sample indices [s0, s1).  mode 'rows': a contiguous band of rows, all sample
+    indices.  The film footprint of a sample crosses rows, which is why every rank keeps a FULL film
+    accumulator and the shards are summed.  'samples' falls back to rows when spp < world.
     The reference's own decomposition hook is Sampler.compute_subwindow
     (sampler/sampler/__init__.py:87-111), unused there (renderer.py:97-109,135)."""
     spp = sampler.xs * sampler.ys
+    if mode == 'interleaved':
+        if world <= 1:
+            return F.tile_desc(sampler.x_start, sampler.x_end, sampler.y_start, sampler.y_end, 0, spp)
+        return F.tile_desc(sampler.x_start, sampler.x_end, sampler.y_start, sampler.y_end, 0, spp, world, rank)
+    if mode not in ('samples', 'rows'):
+        raise ValueError("shard mode must be 'interleaved', 'samples' or 'rows'")
     if mode == 'samples' and spp >= world:
         s0 = (spp * rank) // world
         s1 = (spp * (rank + 1)) // world
@@ -88,7 +99,7 @@ class GpuSamplerRenderer(object):
     """Sample-driven renderer on the GPU; constructor signature of SamplerRenderer (renderer.py:52-56)."""
 
     def __init__(self, s, c, si, vi=None, device=None, seed=0, sampler_mode='device', pretest=False,
-                 shard_mode='samples', write_image=True, image='film', checkpoint=None, checkpoint_every=None,
+                 shard_mode='interleaved', write_image=True, image='film', checkpoint=None, checkpoint_every=None,
                  crop_update='reference', on_piece=None):
         """Beyond the reference's (s, c, si, vi):
 

@@ -77,7 +77,7 @@ class OracleScene(object):
         return prim, t, b1, b2
 
     def render(self, cam, film, sampler, integ, tile, table=None, stats=None, want_L=True):
-        n = (tile.x1 - tile.x0) * (tile.y1 - tile.y0) * (tile.s1 - tile.s0)
+        n = tile.n_samples()
         acc = np.zeros((film.y_cnt, film.x_cnt, 4))
         L = np.zeros((n, 3)) if want_L else None
         dims = 0

@@ -48,8 +48,10 @@ def test_c3_shards_add_up_to_the_one_rank_film(c3):
     whole, s1 = _render(torch, ctx, cam, film, smp, integ, [pa.tile_desc(0, RES, 0, RES, 0, XS * XS)])
     assert s1['camera_samples'] == RES * RES * XS * XS
     scale = float(whole.abs().max())
-    for K, mode in ((2, 'samples'), (8, 'samples'), (4, 'rows')):
+    for K, mode in ((8, 'interleaved'), (3, 'interleaved'), (2, 'samples'), (8, 'samples'), (4, 'rows')):
         tiles = [shard_tile(smp, r, K, mode) for r in range(K)]
+        if mode == 'interleaved':
+            assert sum(t.rows() for t in tiles) == RES and all((t.y_step, t.y_phase) == (K, r) for r, t in enumerate(tiles))
         if mode == 'samples':
             assert [(t.s0, t.s1) for t in tiles] == [(64 * r // K, 64 * (r + 1) // K) for r in range(K)]
         parts, sk = _render(torch, ctx, cam, film, smp, integ, tiles)
@@ -65,9 +67,11 @@ def test_c3_full_size_window_against_the_oracle(c3):
     import oracle_lib as O
     torch, ctx, flat, cam, film, smp, integ = c3
     osc = O.OracleScene(flat)
-    for (x0, y0, w) in ((560, 300, 24), (180, 700, 24)):          # on the head / head silhouette + backdrop
-        wt = pa.tile_desc(x0, x0 + w, y0, y0 + w, 0, XS * XS)
-        n = w * w * XS * XS
+    # on the head / head silhouette + backdrop / every third row of a taller window (an interleaved shard)
+    for (x0, y0, w, h, step, phase) in ((560, 300, 24, 24, 1, 0), (180, 700, 24, 24, 1, 0), (560, 300, 24, 40, 3, 1)):
+        wt = pa.tile_desc(x0, x0 + w, y0, y0 + h, 0, XS * XS, step, phase)
+        n = wt.n_samples()
+        assert n == w * len(range(y0 + phase, y0 + h, step)) * XS * XS
         acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
         L = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
         sg, so = A.pt_stats(), A.pt_stats()

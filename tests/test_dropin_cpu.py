@@ -129,6 +129,18 @@ def test_shard_tile_partitions_exactly():
             assert (t.s0, t.s1) == (0, 8)
             rows[t.y0:t.y1] += 1
         assert (rows[5:50] == 1).all() and rows[:5].sum() == 0
+        # interleaved rows: every row of the window exactly once, all samples, row counts within one of each other
+        rows = np.zeros(50, int)
+        counts = []
+        for r in range(world):
+            t = shard_tile(smp, r, world, 'interleaved')
+            assert (t.x0, t.x1, t.s0, t.s1) == (3, 67, 0, 8)
+            ys = [t.y0 + (t.y_phase if t.y_step > 1 else 0) + k * max(t.y_step, 1) for k in range(t.rows())]
+            assert all(t.y0 <= y < t.y1 for y in ys)
+            rows[ys] += 1
+            counts.append(len(ys))
+            assert t.n_samples() == len(ys) * 64 * 8
+        assert (rows[5:50] == 1).all() and rows[:5].sum() == 0 and max(counts) - min(counts) <= 1
     # spp < world falls back to row bands
     smp1 = pa.sampler_desc(0, 16, 0, 16, 1, 1)
     t = shard_tile(smp1, 1, 2, 'samples')
@@ -160,12 +172,12 @@ def _gloo_worker(rank, world, port, golden_dir, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode', ['samples', 'rows'])
+@pytest.mark.parametrize('mode', ['samples', 'rows', 'interleaved'])
 def test_two_rank_shard_and_reduce_gloo(golden_dir, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if mode == 'rows' else 0)
+    port = 29500 + (os.getpid() % 2000) + {'samples': 0, 'rows': 7, 'interleaved': 13}[mode]
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, golden_dir, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
