@@ -264,6 +264,29 @@ def main():
                          'per link is ~0.2-0.4 ms (SURVEY.md section 5)')
         del other
 
+    # The render runs its any-hit traces on a second stream beside the next closest-hit trace and shading
+    # (PT_OVERLAP, default on), so per-kernel durations of the timed region include the slow-down of sharing the
+    # machine.  For the roofline of the kernel BY ITSELF, two extra steps on a second context with the overlap off
+    # (outside the timed region).
+    excl = None
+    if rank == 0 and world == 1 and os.environ.get('PT_OVERLAP', '1') != '0':
+        os.environ['PT_OVERLAP'] = '0'
+        try:
+            cx = Context(dev.index)
+        finally:
+            del os.environ['PT_OVERLAP']
+        cx.upload(flat)
+        cx.set_profiling(True)
+        accx = torch.zeros_like(acc)
+        cx.render(cam, film, smp, integ, tile, accx, stats=A.pt_stats())
+        excl = A.pt_stats()
+        for _ in range(2):
+            accx.zero_()
+            cx.render(cam, film, smp, integ, tile, accx, stats=excl)
+        torch.cuda.synchronize()
+        cx.close()
+        del accx
+
     if rank == 0:
         # dominant kernel: whichever of the two traversal kernels took more time
         n_any, n_clo = st.rays_any, st.rays_closest
@@ -310,6 +333,17 @@ def main():
                 'rays': int(nr), 'node_visits_per_ray': nv / max(nr, 1), 'tri_tests_per_ray': nt / max(nr, 1),
                 'kernel_Mrays_per_s': nr / (ms * 1e-3) / 1e6 if ms > 0 else 0.0,
                 'stage_ms_per_step': {k: v / args.steps for k, v in st.timing().items()}}
+        if excl is not None:
+            ex_ms, ex_launches = ((excl.ms_trace_closest, excl.launches_trace_closest) if name == 'k_trace<closest>'
+                                  else (excl.ms_trace_any, excl.launches_trace_any))
+            ex_bytes = abytes / max(args.steps, 1) * 2            # the same launches, two steps
+            roof['concurrency'] = ('timed region: any-hit traces run on a second stream beside closest-hit traces and '
+                                   'shading, so `achieved` / `frac` price this kernel while it shares the GPU; '
+                                   '`exclusive` = the same launches with the overlap off (2 extra steps, untimed)')
+            roof['exclusive'] = {'achieved': ex_bytes / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else 0.0,
+                                 'frac': (ex_bytes / (ex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ex_ms > 0 else 0.0,
+                                 'avg_launch_ms': ex_ms / max(ex_launches, 1),
+                                 'stage_ms_per_step': {k: v / 2 for k, v in excl.timing().items()}}
         out = {
             'metric': 'Mrays/s', 'value': rays_total / dt / 1e6, 'unit': 'Mrays/s',
             'samples_per_s': samples_total / dt,

@@ -372,9 +372,6 @@ __device__ inline double blinn_pdf(double e, d3 wo, d3 wi) {
     return ((e + 1.) * pow(ct, e)) / (2. * PT_PI * 4. * dwh);
 }
 
-#ifndef PT_MEAS_ABL
-#define PT_MEAS_ABL 0
-#endif
 // geometry/utility.py:115-122
 __device__ __forceinline__ double spherical_phi(d3 v) {
     double p = atan2(v.y, v.x);
@@ -433,11 +430,7 @@ __device__ __forceinline__ void measured_flush(typename MeasPtr<LDS>::D P, typen
         const d3 d = mk3(P[3 * i], P[3 * i + 1], P[3 * i + 2]) - m;
         const double d2 = d.x * d.x + d.y * d.y + d.z * d.z;
         if (!(d2 <= r2)) continue;           // a list made at a larger radius (phase 1)
-#if PT_MEAS_ABL == 3
-        const double wt = 1. - d2;
-#else
         const double wt = exp(d2 * -100.);
-#endif
         sum_wt += wt;
         v = v + mk3(V[3 * i], V[3 * i + 1], V[3 * i + 2]) * wt;
     }
@@ -479,9 +472,6 @@ __device__ __forceinline__ void measured_scan(typename MeasPtr<LDS>::G gp, typen
 // phase 2 scans ball kf once, lists its samples and weights them.
 template <bool LDS>
 __device__ inline d3 measured_f_as(const char *base_generic, int table, d3 wo, d3 wi, int *hits_generic) {
-#if PT_MEAS_ABL == 1
-    return mk3(.1, .1, .1);
-#endif
     typedef MeasPtr<LDS> MP;
     const typename MP::C base = (typename MP::C)base_generic;
     const lds_int_ptr hits = (lds_int_ptr)hits_generic;

@@ -49,9 +49,12 @@ def main():
                            'workgroup_x, min(grid_x), max(grid_x) from kernels group by name'))
     with open(os.path.join(out, tag + '_kernel_resources.csv'), 'w', newline='') as f:
         w = csv.writer(f)
-        w.writerow(['kernel', 'vgpr', 'agpr', 'sgpr', 'lds_bytes', 'scratch_bytes', 'workgroup', 'grid_min', 'grid_max'])
+        # rocprofv3's vgpr_count on gfx950 is HALF the per-lane allocation (checked against hipcc
+        # -Rpass-analysis=kernel-resource-usage, profiles/r02_resource_usage.txt: k_shade<1,0> 256 vs 128 here, k_splat
+        # 127 -> 128 vs 64, k_raygen 52 -> 56 vs 28): `vgpr` below is the allocation, `vgpr_rocprof` the raw field
+        w.writerow(['kernel', 'vgpr', 'vgpr_rocprof', 'agpr', 'sgpr', 'lds_bytes', 'scratch_bytes', 'workgroup', 'grid_min', 'grid_max'])
         for r in res:
-            w.writerow([short(r[0])] + list(r[1:]))
+            w.writerow([short(r[0]), 2 * r[1], r[1]] + list(r[2:]))
     if len(sys.argv) >= 5:
         agg = {}
         for which, db in (('FETCH_SIZE', sys.argv[3]), ('WRITE_SIZE', sys.argv[4])):
