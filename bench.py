@@ -55,6 +55,9 @@ def parse():
     ap.add_argument('--spp', type=int, default=8, help='strata per axis (spp = spp^2; c5: spp x spp/2)')
     ap.add_argument('--integrator', choices=['path', 'direct'], default='path')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shade-f32', action='store_true',
+                    help='production-only binary32 BSDF / light arithmetic (pt_integrator_desc.shade_f32); the default and '
+                         'the reported headline compute everything in binary64')
     ap.add_argument('--weak', action='store_true', help='N > 1: per-rank sample streams (seed = rank), 64 spp per rank')
     ap.add_argument('--shard-of', default='', help='one GPU: comma list of K; time shard 0 of K for each (scaling proxy)')
     ap.add_argument('--shard-mode', choices=['interleaved', 'samples', 'rows'], default='interleaved')
@@ -183,7 +186,7 @@ def main():
     ctx = Context(dev.index)
     ctx.upload(flat)
     ctx.set_profiling(True)
-    integ = pa.integrator_desc(kind, 5, pretest=False)
+    integ = pa.integrator_desc(kind, 5, pretest=False, shade_f32=args.shade_f32)
     ys = xs if ys is None else ys
     from pytracer_amd.renderer import shard_tile
     strong = world > 1 and not args.weak
@@ -349,7 +352,8 @@ def main():
             'samples_per_s': samples_total / dt,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
+            'dtype': 'f64' if not args.shade_f32 else 'f64 (traversal, points, state, film) + f32 (BSDF / light arithmetic)',
+            'data': 'synthetic',
             'config': {'workload': wname % (xres, yres, xs * ys, 'PathIntegrator' if kind else 'DirectLightingIntegrator'),
                        'triangles': flat.n_tris, 'bvh_nodes': flat.n_nodes,
                        'rays_per_sample': rays_total / max(samples_total, 1),

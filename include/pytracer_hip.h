@@ -188,7 +188,12 @@ typedef struct {
     int32_t pretest;     /* 1: trace the camera any-hit pre-test of renderer.py:168 as a
                             separate ray (its result equals the closest-hit flag);
                             0: skip it (identical image, fewer rays) */
-    int32_t _pad;
+    int32_t shade_f32;   /* 0: every kernel computes in binary64 (the reference's arithmetic; required with a
+                            sample table).  1, production streams only: the BSDF / light ARITHMETIC of the shade
+                            stage (lobe f / pdf / sample_f, Fresnel, pow, sincos, MIS weights) runs in binary32;
+                            points, rays, the sphere-light intersection, every discrete choice made from a
+                            sample value, throughput, radiance and the film stay binary64.  north_star's
+                            tolerance: radiance within 1e-4 relative of the float64 reference */
 } pt_integrator_desc;
 
 /* work shard: pixels [x0,x1)×[y0,y1) of the sampler window, sample indices [s0,s1).

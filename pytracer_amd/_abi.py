@@ -66,7 +66,7 @@ class pt_sampler_desc(C.Structure):
 
 
 class pt_integrator_desc(C.Structure):
-    _fields_ = [('kind', C.c_int32), ('max_depth', C.c_int32), ('pretest', C.c_int32), ('_pad', C.c_int32)]
+    _fields_ = [('kind', C.c_int32), ('max_depth', C.c_int32), ('pretest', C.c_int32), ('shade_f32', C.c_int32)]
 
 
 class pt_tile(C.Structure):

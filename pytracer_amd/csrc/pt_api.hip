@@ -897,6 +897,9 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         return fail(c, PT_ERR_ARG, "integrator kind %d", ig->kind);
     if (cam->kind != PT_CAM_PERSPECTIVE && cam->kind != PT_CAM_ORTHO) return fail(c, PT_ERR_ARG, "camera kind %d", cam->kind);
     if (ig->max_depth < 0 || ig->max_depth > 64) return fail(c, PT_ERR_ARG, "max_depth %d", ig->max_depth);
+    if (ig->shade_f32 != 0 && ig->shade_f32 != 1) return fail(c, PT_ERR_ARG, "shade_f32 %d", ig->shade_f32);
+    if (ig->shade_f32 && sample_table)
+        return fail(c, PT_ERR_ARG, "shade_f32 is production-only: a sample table (parity mode) runs the binary64 kernels");
     if (sp->xs < 1 || sp->ys < 1 || sp->x_end < sp->x_start || sp->y_end < sp->y_start) return fail(c, PT_ERR_ARG, "sampler window");
     const int spp = sp->xs * sp->ys;
     if (tile->x0 < sp->x_start || tile->x1 > sp->x_end || tile->y0 < sp->y_start || tile->y1 > sp->y_end ||
@@ -1007,8 +1010,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
                 StageTimer tm(c, stream, STAGE_SHADE);
                 HIPCHK(c, hipMemsetAsync(c->d_counts + 3 * PT_CNT_BLOCK, 0, PT_CNT_BLOCK * sizeof(int), stream));
                 HIPCHK(c, pt_launch_list_hits(gs * 2, stream, qin, hit_list(level)));
-                HIPCHK(c, pt_launch_shade(ig->kind, gs, stream, c->sc, c->d_rc, base, level, qin, hit_list(level), qout,
-                                          sh, c->st));
+                HIPCHK(c, pt_launch_shade(ig->kind, ig->shade_f32 != 0, gs, stream, c->sc, c->d_rc, base, level, qin,
+                                          hit_list(level), qout, sh, c->st));
             }
             ShadowResolve rs = {sh.c, sh.stride, sh.slot, c->st.L, c->st.stride};
             hipStream_t any_stream = stream;

@@ -25,34 +25,42 @@
 #define BDF_SPECULAR 16u
 #define BDF_ALL 31u
 
-struct d3 {
-    double x, y, z;
+template <typename R> struct v3 {
+    R x, y, z;
 };
+typedef v3<double> d3;
 
-__device__ __forceinline__ d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ d3 operator-(d3 a) { return mk3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ d3 operator*(d3 a, double s) { return mk3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ d3 operator*(d3 a, d3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <typename R> __device__ __forceinline__ v3<R> mkv(R x, R y, R z) { v3<R> r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3 mk3(double x, double y, double z) { return mkv<double>(x, y, z); }
+template <typename R, typename S> __device__ __forceinline__ v3<R> cvt3(v3<S> a) { return mkv<R>((R)a.x, (R)a.y, (R)a.z); }
+template <typename R> __device__ __forceinline__ v3<R> operator+(v3<R> a, v3<R> b) { return mkv<R>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename R> __device__ __forceinline__ v3<R> operator-(v3<R> a, v3<R> b) { return mkv<R>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename R> __device__ __forceinline__ v3<R> operator-(v3<R> a) { return mkv<R>(-a.x, -a.y, -a.z); }
+template <typename R> __device__ __forceinline__ v3<R> operator*(v3<R> a, R s) { return mkv<R>(a.x * s, a.y * s, a.z * s); }
+template <typename R> __device__ __forceinline__ v3<R> operator*(v3<R> a, v3<R> b) { return mkv<R>(a.x * b.x, a.y * b.y, a.z * b.z); }
 __device__ __forceinline__ d3 operator/(d3 a, double s) { return mk3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ v3<float> operator/(v3<float> a, float s) {       // production variant: one reciprocal (1 ulp)
+    const float r = __frcp_rn(s);
+    return mkv<float>(a.x * r, a.y * r, a.z * r);
+}
 // ndarray.dot on 3-vectors: left-to-right accumulation
-__device__ __forceinline__ double dot3(d3 a, d3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+template <typename R> __device__ __forceinline__ R dot3(v3<R> a, v3<R> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 // Vector.cross, geometry/__init__.py:79-82
-__device__ __forceinline__ d3 cross3(d3 a, d3 b) {
-    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+template <typename R> __device__ __forceinline__ v3<R> cross3(v3<R> a, v3<R> b) {
+    return mkv<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 // sq_length / length, geometry/__init__.py:84-88
-__device__ __forceinline__ double sqlen3(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+template <typename R> __device__ __forceinline__ R sqlen3(v3<R> a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 __device__ __forceinline__ double len3(d3 a) { return sqrt(sqlen3(a)); }
+__device__ __forceinline__ float len3(v3<float> a) { return sqrtf(sqlen3(a)); }
 // geometry/utility.py:55-73
-__device__ __forceinline__ d3 normalize3(d3 a) {
-    double l = len3(a);
-    if (!(l == 0.0)) return a / l;
+template <typename R> __device__ __forceinline__ v3<R> normalize3(v3<R> a) {
+    R l = len3(a);
+    if (!(l == R(0))) return a / l;
     return a;
 }
-__device__ __forceinline__ double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
-__device__ __forceinline__ double max0(double x) { return x > 0.0 ? x : 0.0; }
+template <typename R> __device__ __forceinline__ R clipd(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
+template <typename R> __device__ __forceinline__ R max0(R x) { return x > R(0) ? x : R(0); }
 
 // counter-based uniform in [0,1): splitmix64 finaliser of (sid, k); DESIGN.md "sample streams"
 __device__ __forceinline__ double hash_uniform(uint32_t sid, uint32_t k) {
@@ -304,12 +312,57 @@ __device__ inline void apply_textures(const DScene &sc, Vertex &vx, int prim, do
     vx.mat = scratch;
 }
 
+// ---------------------------------------------------------------------------------------
+// BSDF and light arithmetic, generic in the real type R.  R = double restates the reference operation for
+// operation (the parity kernels); R = float is the production-only fast variant (k_shade<KIND, EXT, float>):
+// directions, colours, pdfs and the transcendental functions in binary32, while POINTS — the vertex, the point
+// sampled on a light, everything a ray is built from — and every discrete decision that geometry feeds (inside /
+// outside the light sphere, the sphere intersection) stay binary64, as do throughput, radiance and the film.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double r_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float r_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double r_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float r_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double r_pow(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ float r_pow(float x, float y) { return __powf(x, y); }          // exp2(y log2 x): ~2e-6 relative here
+__device__ __forceinline__ void r_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+__device__ __forceinline__ void r_sincos(float x, float *s, float *c) { __sincosf(x, s, c); }   // arguments in [0, 2 pi]
+// binary64: IEEE division, as numpy divides.  binary32 (production variant): multiplication by v_rcp_f32 (1 ulp)
+__device__ __forceinline__ double r_div(double a, double b) { return a / b; }
+__device__ __forceinline__ float r_div(float a, float b) { return a * __frcp_rn(b); }
+__device__ __forceinline__ double r_acos(double x) { return acos(x); }
+__device__ __forceinline__ float r_acos(float x) { return acosf(x); }
+__device__ __forceinline__ double r_sin(double x) { return sin(x); }
+__device__ __forceinline__ float r_sin(float x) { return sinf(x); }
+__device__ __forceinline__ double r_cos(double x) { return cos(x); }
+__device__ __forceinline__ float r_cos(float x) { return cosf(x); }
+
+template <typename R> struct VertexT {
+    d3 p;                      // the shading point: always binary64
+    v3<R> nn, sn, tn;
+    double rEps;
+    const pt_material *mat;
+    const char *brdf;          // the BrdfGrid blob, in HBM or staged in LDS (read by k_shade<KIND, 2> only)
+    bool brdf_in_lds;
+    int *hits;                 // this thread's hit list in LDS (measured_f; k_shade<KIND, 2> only)
+};
+template <typename R>
+__device__ __forceinline__ VertexT<R> vertex_as(const Vertex &vx) {
+    VertexT<R> v;
+    v.p = vx.p;
+    v.nn = cvt3<R>(vx.nn); v.sn = cvt3<R>(vx.sn); v.tn = cvt3<R>(vx.tn);
+    v.rEps = vx.rEps; v.mat = vx.mat; v.brdf = vx.brdf; v.brdf_in_lds = vx.brdf_in_lds; v.hits = vx.hits;
+    return v;
+}
+
 // BSDF.w2l, bsdf.py:187-194
-__device__ __forceinline__ d3 w2l(const Vertex &vx, d3 v) { return mk3(dot3(v, vx.sn), dot3(v, vx.tn), dot3(v, vx.nn)); }
+template <typename R>
+__device__ __forceinline__ v3<R> w2l(const VertexT<R> &vx, v3<R> v) { return mkv<R>(dot3(v, vx.sn), dot3(v, vx.tn), dot3(v, vx.nn)); }
 // BSDF.l2w AS WRITTEN, bsdf.py:196-205 (each basis vector scaled by the same component)
-__device__ __forceinline__ d3 l2w(const Vertex &vx, d3 v) {
-    return mk3(vx.sn.x * v.x + vx.tn.x * v.x + vx.nn.x * v.x, vx.sn.y * v.y + vx.tn.y * v.y + vx.nn.y * v.y,
-               vx.sn.z * v.z + vx.tn.z * v.z + vx.nn.z * v.z);
+template <typename R>
+__device__ __forceinline__ v3<R> l2w(const VertexT<R> &vx, v3<R> v) {
+    return mkv<R>(vx.sn.x * v.x + vx.tn.x * v.x + vx.nn.x * v.x, vx.sn.y * v.y + vx.tn.y * v.y + vx.nn.y * v.y,
+                  vx.sn.z * v.z + vx.tn.z * v.z + vx.nn.z * v.z);
 }
 
 __device__ __forceinline__ unsigned lobe_flags(int type) {
@@ -327,49 +380,53 @@ __device__ __forceinline__ bool match_flag(int type, unsigned flags) {
 }
 
 // fr_diel AS WRITTEN, reflection/utility.py:46-57 (Q8)
-__device__ __forceinline__ double fr_diel(double cos_i, double cos_t, double eta_i, double eta_t) {
-    double r_para = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_t * cos_t));
-    double r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
-    return .5 * (r_para * r_para + r_perp * r_perp);
+template <typename R>
+__device__ __forceinline__ R fr_diel(R cos_i, R cos_t, R eta_i, R eta_t) {
+    R r_para = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_t * cos_t));
+    R r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+    return R(.5) * (r_para * r_para + r_perp * r_perp);
 }
 // FresnelDielectric.__call__, reflection/fresnel.py:54-72
-__device__ inline double fresnel_dielectric(double cosi, double eta_i, double eta_t) {
-    double ci = clipd(cosi, -1., 1.);
-    double ei = eta_i, et = eta_t;
-    if (cosi < 0.) { double tmp = ei; ei = et; et = tmp; }
-    double st = ei / et * sqrt(max0(1. - ci * ci));
-    if (st >= 1.) return 1.;
-    double ct = sqrt(max0(1. - st * st));
-    return fr_diel(fabs(ci), ct, ei, et);
+template <typename R>
+__device__ inline R fresnel_dielectric(R cosi, R eta_i, R eta_t) {
+    R ci = clipd(cosi, R(-1), R(1));
+    R ei = eta_i, et = eta_t;
+    if (cosi < R(0)) { R tmp = ei; ei = et; et = tmp; }
+    R st = ei / et * r_sqrt(max0(R(1) - ci * ci));
+    if (st >= R(1)) return R(1);
+    R ct = r_sqrt(max0(R(1) - st * st));
+    return fr_diel(r_abs(ci), ct, ei, et);
 }
 
 // fr_cond, reflection/utility.py:60-73, one channel; FresnelConductor.__call__ passes |cos| (fresnel.py:40-41)
-__device__ __forceinline__ double fr_cond(double cos_i, double eta, double k) {
-    double tmp = (eta * eta + k * k) * cos_i * cos_i;
-    double r_para_sq = (tmp - (2. * eta * cos_i) + 1.) / (tmp + (2. * eta * cos_i) + 1.);
+template <typename R>
+__device__ __forceinline__ R fr_cond(R cos_i, R eta, R k) {
+    R tmp = (eta * eta + k * k) * cos_i * cos_i;
+    R r_para_sq = (tmp - (R(2) * eta * cos_i) + R(1)) / (tmp + (R(2) * eta * cos_i) + R(1));
     tmp = eta * eta + k * k;
-    double r_perp_sq = (tmp - (2. * eta * cos_i) + cos_i * cos_i) / (tmp + (2. * eta * cos_i) + cos_i * cos_i);
-    return .5 * (r_para_sq + r_perp_sq);
+    R r_perp_sq = (tmp - (R(2) * eta * cos_i) + cos_i * cos_i) / (tmp + (R(2) * eta * cos_i) + cos_i * cos_i);
+    return R(.5) * (r_para_sq + r_perp_sq);
 }
 
 // reflection/utility.py:31-42
-__device__ __forceinline__ double sin_theta(d3 w) { return sqrt(max0(1. - w.z * w.z)); }
-__device__ __forceinline__ double cos_phi(d3 w) {
-    double s2 = max0(1. - w.z * w.z);
-    return s2 == 0. ? 1. : clipd(w.x / sqrt(s2), -1., 1.);
+template <typename R> __device__ __forceinline__ R sin_theta(v3<R> w) { return r_sqrt(max0(R(1) - w.z * w.z)); }
+template <typename R> __device__ __forceinline__ R cos_phi(v3<R> w) {
+    R s2 = max0(R(1) - w.z * w.z);
+    return s2 == R(0) ? R(1) : clipd(w.x / r_sqrt(s2), R(-1), R(1));
 }
-__device__ __forceinline__ double sin_phi(d3 w) {
-    double s2 = max0(1. - w.z * w.z);
-    return s2 == 0. ? 0. : clipd(w.y / sqrt(s2), -1., 1.);
+template <typename R> __device__ __forceinline__ R sin_phi(v3<R> w) {
+    R s2 = max0(R(1) - w.z * w.z);
+    return s2 == R(0) ? R(0) : clipd(w.y / r_sqrt(s2), R(-1), R(1));
 }
 
 // Blinn.pdf, reflection/bdf/torrance.py:95-102
-__device__ inline double blinn_pdf(double e, d3 wo, d3 wi) {
-    d3 wh = normalize3(wo + wi);
-    double ct = fabs(wh.z);
-    double dwh = dot3(wo, wh);
-    if (dwh <= 0.) return 0.;
-    return ((e + 1.) * pow(ct, e)) / (2. * PT_PI * 4. * dwh);
+template <typename R>
+__device__ inline R blinn_pdf(R e, v3<R> wo, v3<R> wi) {
+    v3<R> wh = normalize3(wo + wi);
+    R ct = r_abs(wh.z);
+    R dwh = dot3(wo, wh);
+    if (dwh <= R(0)) return R(0);
+    return ((e + R(1)) * r_pow(ct, e)) / (R(2) * R(PT_PI) * R(4) * dwh);
 }
 
 // geometry/utility.py:115-122
@@ -537,202 +594,210 @@ __device__ inline d3 measured_f(const char *base, bool in_lds, int table, d3 wo,
 
 // EXT (here and below): the shade kernels that scenes with measured lobes run (k_shade<KIND, 2>, pt_launch_shade);
 // the measured lobe is compiled into those only, so that the other kernels keep their registers
-template <bool EXT>
-__device__ inline d3 lobe_f(const pt_lobe &l, d3 wo, d3 wi, const Vertex &vx) {
-    d3 R = mk3(l.R[0], l.R[1], l.R[2]);
-    if (EXT && l.type == PT_LOBE_MEASURED_IRISO) return measured_f(vx.brdf, vx.brdf_in_lds, (int)l.a, wo, wi, vx.hits);
+template <bool EXT, typename R>
+__device__ inline v3<R> lobe_f(const pt_lobe &l, v3<R> wo, v3<R> wi, const VertexT<R> &vx) {
+    v3<R> Rc = mkv<R>((R)l.R[0], (R)l.R[1], (R)l.R[2]);
+    if (EXT && l.type == PT_LOBE_MEASURED_IRISO)      // the table walk is binary64 in every variant
+        return cvt3<R>(measured_f(vx.brdf, vx.brdf_in_lds, (int)l.a, cvt3<double>(wo), cvt3<double>(wi), vx.hits));
     switch (l.type) {
     case PT_LOBE_LAMBERT:   // bdf.py:327-332
-        return R * PT_INV_PI;
+        return Rc * R(PT_INV_PI);
     case PT_LOBE_OREN_NAYAR: {   // orennayar.py:44-62
-        double st_i = sin_theta(wi), st_o = sin_theta(wo);
-        double mc = 0.;
-        if (st_i > PT_EPS && st_o > PT_EPS) {
-            double dcos = cos_phi(wi) * cos_phi(wo) + sin_phi(wi) * sin_phi(wo);
+        R st_i = sin_theta(wi), st_o = sin_theta(wo);
+        R mc = R(0);
+        if (st_i > R(PT_EPS) && st_o > R(PT_EPS)) {
+            R dcos = cos_phi(wi) * cos_phi(wo) + sin_phi(wi) * sin_phi(wo);
             mc = max0(dcos);
         }
-        double sa, tb;
-        if (fabs(wi.z) > fabs(wo.z)) { sa = st_o; tb = st_i / fabs(wi.z); }
-        else { sa = st_i; tb = st_o / fabs(wo.z); }
-        return (R * PT_INV_PI) * (l.a + l.b * mc * sa * tb);
+        R sa, tb;
+        if (r_abs(wi.z) > r_abs(wo.z)) { sa = st_o; tb = st_i / r_abs(wi.z); }
+        else { sa = st_i; tb = st_o / r_abs(wo.z); }
+        return (Rc * R(PT_INV_PI)) * ((R)l.a + (R)l.b * mc * sa * tb);
     }
     case PT_LOBE_MICROFACET_BLINN:
     case PT_LOBE_MICROFACET_BLINN_COND: {   // torrance.py:200-216, Blinn.D :69-70
-        double ct_i = wi.z, ct_o = wo.z;
-        if (ct_i == 0. || ct_o == 0.) return mk3(0, 0, 0);
-        d3 wh = normalize3(wi + wo);
-        double ct_h = dot3(wi, wh);
-        double awh = fabs(wh.z), adot = fabs(dot3(wo, wh));
-        double g1 = 2. * awh * fabs(wo.z) / adot, g2 = 2. * awh * fabs(wi.z) / adot;
-        double gm = (g2 < g1) ? g2 : g1;
-        double G = (gm < 1.) ? gm : 1.;
-        double D = (l.c + 2) * PT_INV_2PI * pow(awh, l.c);
+        R ct_i = wi.z, ct_o = wo.z;
+        if (ct_i == R(0) || ct_o == R(0)) return mkv<R>(R(0), R(0), R(0));
+        v3<R> wh = normalize3(wi + wo);
+        R ct_h = dot3(wi, wh);
+        R awh = r_abs(wh.z), adot = r_abs(dot3(wo, wh));
+        R g1 = R(2) * awh * r_abs(wo.z) / adot, g2 = R(2) * awh * r_abs(wi.z) / adot;
+        R gm = (g2 < g1) ? g2 : g1;
+        R G = (gm < R(1)) ? gm : R(1);
+        R D = ((R)l.c + R(2)) * R(PT_INV_2PI) * r_pow(awh, (R)l.c);
         if (l.type == PT_LOBE_MICROFACET_BLINN_COND) {   // Spectrum-valued Fresnel term (MetalMaterial)
-            const double ch = fabs(ct_h);
-            d3 F = mk3(fr_cond(ch, l.eta[0], l.k[0]), fr_cond(ch, l.eta[1], l.k[1]), fr_cond(ch, l.eta[2], l.k[2]));
-            return (((R * D) * G) * F) / (4. * ct_i * ct_o);
+            const R ch = r_abs(ct_h);
+            v3<R> F = mkv<R>(fr_cond(ch, (R)l.eta[0], (R)l.k[0]), fr_cond(ch, (R)l.eta[1], (R)l.k[1]),
+                             fr_cond(ch, (R)l.eta[2], (R)l.k[2]));
+            return (((Rc * D) * G) * F) / (R(4) * ct_i * ct_o);
         }
-        double F = fresnel_dielectric(ct_h, l.a, l.b);
-        return (((R * D) * G) * F) / (4. * ct_i * ct_o);
+        R F = fresnel_dielectric(ct_h, (R)l.a, (R)l.b);
+        return (((Rc * D) * G) * F) / (R(4) * ct_i * ct_o);
     }
     default:   // specular lobes evaluate to 0, bdf.py:241-246,274-279
-        return mk3(0, 0, 0);
+        return mkv<R>(R(0), R(0), R(0));
     }
 }
 
 // BDF.pdf (bdf.py:97-106), Microfacet.pdf (torrance.py:225-228), specular → 0
-__device__ inline double lobe_pdf(const pt_lobe &l, d3 wo, d3 wi) {
+template <typename R>
+__device__ inline R lobe_pdf(const pt_lobe &l, v3<R> wo, v3<R> wi) {
     switch (l.type) {
     case PT_LOBE_LAMBERT:
     case PT_LOBE_OREN_NAYAR:
     case PT_LOBE_MEASURED_IRISO:
-        return (wo.z * wi.z > 0.) ? fabs(wi.z) * PT_INV_PI : 0.;
+        return (wo.z * wi.z > R(0)) ? r_abs(wi.z) * R(PT_INV_PI) : R(0);
     case PT_LOBE_MICROFACET_BLINN:
     case PT_LOBE_MICROFACET_BLINN_COND:
-        if (wi.z * wo.z <= 0.) return 0.;
-        return blinn_pdf(l.c, wo, wi);
+        if (wi.z * wo.z <= R(0)) return R(0);
+        return blinn_pdf((R)l.c, wo, wi);
     default:
-        return 0.;
+        return R(0);
     }
 }
 
-template <bool EXT>
-__device__ inline double lobe_sample_f(const pt_lobe &l, d3 wo, double u1, double u2, d3 &wi_out, d3 &f_out,
-                                       const Vertex &vx) {
-    d3 R = mk3(l.R[0], l.R[1], l.R[2]);
+template <bool EXT, typename R>
+__device__ inline R lobe_sample_f(const pt_lobe &l, v3<R> wo, R u1, R u2, v3<R> &wi_out, v3<R> &f_out,
+                                  const VertexT<R> &vx) {
+    v3<R> Rc = mkv<R>((R)l.R[0], (R)l.R[1], (R)l.R[2]);
     switch (l.type) {
     case PT_LOBE_LAMBERT:
     case PT_LOBE_OREN_NAYAR:
     case PT_LOBE_MEASURED_IRISO: {
         // BDF.sample_f (bdf.py:108-126); cosine_sample_hemisphere AS WRITTEN
         // (montecarlo/utility.py:171-184 on top of uniform_sample_sphere :83-95; Q6)
-        double z = 1. - 2. * u1;
-        double r = sqrt(max0(1. - z * z));
-        double phi = 2. * PT_PI * u2, sphi, cphi;
-        sincos(phi, &sphi, &cphi);
-        d3 wi = mk3(r * cphi, r * sphi, z);
-        wi.z = sqrt(max0(1. - wi.x * wi.x - wi.y * wi.y));
-        if (wo.z < 0.) wi.z *= -1.;
+        R z = R(1) - R(2) * u1;
+        R r = r_sqrt(max0(R(1) - z * z));
+        R phi = R(2) * R(PT_PI) * u2, sphi, cphi;
+        r_sincos(phi, &sphi, &cphi);
+        v3<R> wi = mkv<R>(r * cphi, r * sphi, z);
+        // sqrt(1 - x^2 - y^2) is |z| up to rounding; in binary32 the subtraction cancels for grazing directions
+        // (relative error 6e-8 / z^2: 1e-4 already at |z| = 0.025, 2.5 % of these samples), so that variant takes |z|
+        if (sizeof(R) == 4) wi.z = r_abs(z);
+        else wi.z = r_sqrt(max0(R(1) - wi.x * wi.x - wi.y * wi.y));
+        if (wo.z < R(0)) wi.z *= R(-1);
         wi_out = wi;
         f_out = lobe_f<EXT>(l, wo, wi, vx);
         return lobe_pdf(l, wo, wi);
     }
     case PT_LOBE_MICROFACET_BLINN:
     case PT_LOBE_MICROFACET_BLINN_COND: {   // torrance.py:218-223, Blinn.sample_f :72-93
-        double e = l.c;
-        double ct = pow(u1, 1. / (e + 1));
-        double st = sqrt(max0(1. - ct * ct));
-        double phi = u2 * 2. * PT_PI, sphi, cphi;
-        sincos(phi, &sphi, &cphi);
-        d3 wh = mk3(st * cphi, st * sphi, ct);
-        if (wo.z * wh.z <= 0.) wh = wh * -1.;
-        double dwh = dot3(wo, wh);
-        d3 wi = (-wo) + (wh * (2. * dwh));
-        double pdf = ((e + 1.) * pow(ct, e)) / (2. * PT_PI * 4. * dwh);
-        if (dwh <= 0.) pdf = 0.;
+        R e = (R)l.c;
+        R ct = r_pow(u1, R(1) / (e + R(1)));
+        R st = r_sqrt(max0(R(1) - ct * ct));
+        R phi = u2 * R(2) * R(PT_PI), sphi, cphi;
+        r_sincos(phi, &sphi, &cphi);
+        v3<R> wh = mkv<R>(st * cphi, st * sphi, ct);
+        if (wo.z * wh.z <= R(0)) wh = wh * R(-1);
+        R dwh = dot3(wo, wh);
+        v3<R> wi = (-wo) + (wh * (R(2) * dwh));
+        R pdf = ((e + R(1)) * r_pow(ct, e)) / (R(2) * R(PT_PI) * R(4) * dwh);
+        if (dwh <= R(0)) pdf = R(0);
         wi_out = wi;
-        if (wi.z * wo.z <= 0.) f_out = mk3(0, 0, 0);
+        if (wi.z * wo.z <= R(0)) f_out = mkv<R>(R(0), R(0), R(0));
         else f_out = lobe_f<EXT>(l, wo, wi, vx);
         return pdf;
     }
     case PT_LOBE_SPEC_REFLECT: {   // bdf.py:251-256
-        d3 wi = mk3(-wo.x, -wo.y, wo.z);
-        double F = (l.c != 0.) ? 1. : fresnel_dielectric(wo.z, l.a, l.b);
+        v3<R> wi = mkv<R>(-wo.x, -wo.y, wo.z);
+        R F = (l.c != 0.) ? R(1) : fresnel_dielectric(wo.z, (R)l.a, (R)l.b);
         wi_out = wi;
-        f_out = (R * F) / fabs(wi.z);
-        return 1.;
+        f_out = (Rc * F) / r_abs(wi.z);
+        return R(1);
     }
     default: {   // SpecularTransmission.sample_f, bdf.py:284-307
-        double ei = l.a, et = l.b;
-        if (wo.z > 0.) { double tmp = ei; ei = et; et = tmp; }
-        double si_sq = max0(1. - wo.z * wo.z);
-        double eta = ei / et;
-        double st_sq = eta * eta * si_sq;
-        if (st_sq >= 1.) return 0.;
-        double ct = sqrt(max0(1. - st_sq));
-        if (wo.z > 0.) ct = -ct;
-        d3 wi = mk3(eta * (-wo.x), eta * (-wo.y), ct);
-        double F = fresnel_dielectric(wo.z, l.a, l.b);
+        R ei = (R)l.a, et = (R)l.b;
+        if (wo.z > R(0)) { R tmp = ei; ei = et; et = tmp; }
+        R si_sq = max0(R(1) - wo.z * wo.z);
+        R eta = ei / et;
+        R st_sq = eta * eta * si_sq;
+        if (st_sq >= R(1)) return R(0);
+        R ct = r_sqrt(max0(R(1) - st_sq));
+        if (wo.z > R(0)) ct = -ct;
+        v3<R> wi = mkv<R>(eta * (-wo.x), eta * (-wo.y), ct);
+        R F = fresnel_dielectric(wo.z, (R)l.a, (R)l.b);
         wi_out = wi;
-        f_out = (R * ((et * et) / (ei * ei) * (1. - F))) / fabs(wi.z);
-        return 1.;
+        f_out = (Rc * ((et * et) / (ei * ei) * (R(1) - F))) / r_abs(wi.z);
+        return R(1);
     }
     }
 }
 
 // BSDF.f, bsdf.py:207-224
-template <bool EXT>
-__device__ inline d3 bsdf_f(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned flags) {
-    d3 wi = w2l(vx, wi_w), wo = w2l(vx, wo_w);
-    if (dot3(wi_w, vx.nn) * dot3(wo_w, vx.nn) > 0.) flags &= ~BDF_TRANSMISSION;
+template <bool EXT, typename R>
+__device__ inline v3<R> bsdf_f(const VertexT<R> &vx, v3<R> wo_w, v3<R> wi_w, unsigned flags) {
+    v3<R> wi = w2l(vx, wi_w), wo = w2l(vx, wo_w);
+    if (dot3(wi_w, vx.nn) * dot3(wo_w, vx.nn) > R(0)) flags &= ~BDF_TRANSMISSION;
     else flags &= ~BDF_REFLECTION;
-    d3 f = mk3(0, 0, 0);
+    v3<R> f = mkv<R>(R(0), R(0), R(0));
     for (int i = 0; i < vx.mat->n_lobes; i++)
         if (match_flag(vx.mat->lobes[i].type, flags)) f = f + lobe_f<EXT>(vx.mat->lobes[i], wo, wi, vx);
     return f;
 }
 
 // BSDF.pdf, bsdf.py:156-167
-__device__ inline double bsdf_pdf(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned flags) {
-    if (vx.mat->n_lobes == 0) return 0.;
-    d3 wo = w2l(vx, wo_w), wi = w2l(vx, wi_w);
-    double pdf = 0.;
+template <typename R>
+__device__ inline R bsdf_pdf(const VertexT<R> &vx, v3<R> wo_w, v3<R> wi_w, unsigned flags) {
+    if (vx.mat->n_lobes == 0) return R(0);
+    v3<R> wo = w2l(vx, wo_w), wi = w2l(vx, wi_w);
+    R pdf = R(0);
     int n_match = 0;
     for (int i = 0; i < vx.mat->n_lobes; i++)
         if (match_flag(vx.mat->lobes[i].type, flags)) { n_match++; pdf += lobe_pdf(vx.mat->lobes[i], wo, wi); }
-    return n_match > 0 ? pdf / n_match : 0.;
+    return n_match > 0 ? pdf / n_match : R(0);
 }
 
 // BSDF.f and BSDF.pdf for the same pair of directions (estimate_direct evaluates both,
 // integrator/utility.py:221-231).  Same values as bsdf_f / bsdf_pdf; a Blinn microfacet lobe computes
 // its half vector and |cos θh|^e once for both (pow is the most expensive call of the vertex).
-template <bool EXT>
-__device__ inline d3 bsdf_f_pdf(const Vertex &vx, d3 wo_w, d3 wi_w, unsigned flags, double &pdf_out) {
-    d3 wi = w2l(vx, wi_w), wo = w2l(vx, wo_w);
+template <bool EXT, typename R>
+__device__ inline v3<R> bsdf_f_pdf(const VertexT<R> &vx, v3<R> wo_w, v3<R> wi_w, unsigned flags, R &pdf_out) {
+    v3<R> wi = w2l(vx, wi_w), wo = w2l(vx, wo_w);
     unsigned fflags = flags;
-    if (dot3(wi_w, vx.nn) * dot3(wo_w, vx.nn) > 0.) fflags &= ~BDF_TRANSMISSION;
+    if (dot3(wi_w, vx.nn) * dot3(wo_w, vx.nn) > R(0)) fflags &= ~BDF_TRANSMISSION;
     else fflags &= ~BDF_REFLECTION;
-    d3 f = mk3(0, 0, 0);
-    double pdf = 0.;
+    v3<R> f = mkv<R>(R(0), R(0), R(0));
+    R pdf = R(0);
     int n_match = 0;
     for (int i = 0; i < vx.mat->n_lobes; i++) {
         const pt_lobe &l = vx.mat->lobes[i];
         const bool mf = match_flag(l.type, fflags), mp = match_flag(l.type, flags);
-        if (l.type == PT_LOBE_MICROFACET_BLINN && mf && mp && wi.z != 0. && wo.z != 0. && wi.z * wo.z > 0.) {
+        if (l.type == PT_LOBE_MICROFACET_BLINN && mf && mp && wi.z != R(0) && wo.z != R(0) && wi.z * wo.z > R(0)) {
             // lobe_f and blinn_pdf share wh = normalize(wo + wi) (addition commutes) and pow(|wh.z|, e)
-            d3 R = mk3(l.R[0], l.R[1], l.R[2]);
-            d3 wh = normalize3(wi + wo);
-            double ct_h = dot3(wi, wh);
-            double F = fresnel_dielectric(ct_h, l.a, l.b);
-            double awh = fabs(wh.z), dwh = dot3(wo, wh), adot = fabs(dwh);
-            double g1 = 2. * awh * fabs(wo.z) / adot, g2 = 2. * awh * fabs(wi.z) / adot;
-            double gm = (g2 < g1) ? g2 : g1;
-            double G = (gm < 1.) ? gm : 1.;
-            double pw = pow(awh, l.c);
-            double D = (l.c + 2) * PT_INV_2PI * pw;
-            f = f + (((R * D) * G) * F) / (4. * wi.z * wo.z);
+            v3<R> Rc = mkv<R>((R)l.R[0], (R)l.R[1], (R)l.R[2]);
+            v3<R> wh = normalize3(wi + wo);
+            R ct_h = dot3(wi, wh);
+            R F = fresnel_dielectric(ct_h, (R)l.a, (R)l.b);
+            R awh = r_abs(wh.z), dwh = dot3(wo, wh), adot = r_abs(dwh);
+            R g1 = R(2) * awh * r_abs(wo.z) / adot, g2 = R(2) * awh * r_abs(wi.z) / adot;
+            R gm = (g2 < g1) ? g2 : g1;
+            R G = (gm < R(1)) ? gm : R(1);
+            R pw = r_pow(awh, (R)l.c);
+            R D = ((R)l.c + R(2)) * R(PT_INV_2PI) * pw;
+            f = f + (((Rc * D) * G) * F) / (R(4) * wi.z * wo.z);
             n_match++;
-            if (dwh > 0.) pdf += ((l.c + 1.) * pw) / (2. * PT_PI * 4. * dwh);
+            if (dwh > R(0)) pdf += (((R)l.c + R(1)) * pw) / (R(2) * R(PT_PI) * R(4) * dwh);
             continue;
         }
         if (mf) f = f + lobe_f<EXT>(l, wo, wi, vx);
         if (mp) { n_match++; pdf += lobe_pdf(l, wo, wi); }
     }
-    pdf_out = n_match > 0 ? pdf / n_match : 0.;
+    pdf_out = n_match > 0 ? pdf / n_match : R(0);
     return f;
 }
 
 // BSDF.sample_f AS IT EXECUTES, bsdf.py:100-154: `bdf.type & SPECULAR` is an object, always
 // truthy, so the pdf sum (:132-135) and the f re-evaluation (:141-152) never run (Q2).
-template <bool EXT>
-__device__ inline double bsdf_sample_f(const Vertex &vx, d3 wo_w, double u0, double u1, double u_com, unsigned flags,
-                                       d3 &wi_w, d3 &f) {
+// u_com picks the lobe: binary64 in every variant (a discrete decision).
+template <bool EXT, typename R>
+__device__ inline R bsdf_sample_f(const VertexT<R> &vx, v3<R> wo_w, R u0, R u1, double u_com, unsigned flags,
+                                  v3<R> &wi_w, v3<R> &f) {
     const pt_material *m = vx.mat;
     int n_match = 0;
     for (int i = 0; i < m->n_lobes; i++) n_match += match_flag(m->lobes[i].type, flags) ? 1 : 0;
-    f = mk3(0, 0, 0);
-    wi_w = mk3(0, 0, 0);
-    if (n_match == 0) return 0.;
+    f = mkv<R>(R(0), R(0), R(0));
+    wi_w = mkv<R>(R(0), R(0), R(0));
+    if (n_match == 0) return R(0);
     int cnt = (int)floor(u_com * n_match);
     if (cnt > n_match - 1) cnt = n_match - 1;
     int pick = -1;
@@ -741,10 +806,10 @@ __device__ inline double bsdf_sample_f(const Vertex &vx, d3 wo_w, double u0, dou
             if (cnt == 0) { pick = i; break; }
             cnt--;
         }
-    if (pick < 0) return 0.;
-    d3 wo = w2l(vx, wo_w), wi, fl;
-    double pdf = lobe_sample_f<EXT>(m->lobes[pick], wo, u0, u1, wi, fl, vx);
-    if (pdf == 0.) return 0.;
+    if (pick < 0) return R(0);
+    v3<R> wo = w2l(vx, wo_w), wi, fl;
+    R pdf = lobe_sample_f<EXT>(m->lobes[pick], wo, u0, u1, wi, fl, vx);
+    if (pdf == R(0)) return R(0);
     wi_w = l2w(vx, wi);
     if (n_match > 1) pdf /= n_match;
     f = fl;
@@ -769,19 +834,21 @@ __device__ __forceinline__ d3 xf_normal(const double *minv, d3 n) {
 }
 
 // geometry/utility.py:25-52
-__device__ inline void coordinate_system(d3 v1, d3 &v2, d3 &v3) {
-    if (len3(v1) == 0.) { v2 = mk3(0, 1, 0); v3 = mk3(0, 0, 1); return; }
-    if (fabs(v1.x) > fabs(v1.y)) {
-        double inv_len = 1. / sqrt(v1.x * v1.x + v1.z * v1.z);
-        v2 = mk3(-v1.z * inv_len, 0., v1.x * inv_len);
+template <typename R>
+__device__ inline void coordinate_system(v3<R> v1, v3<R> &v2, v3<R> &v3_) {
+    if (len3(v1) == R(0)) { v2 = mkv<R>(R(0), R(1), R(0)); v3_ = mkv<R>(R(0), R(0), R(1)); return; }
+    if (r_abs(v1.x) > r_abs(v1.y)) {
+        R inv_len = R(1) / r_sqrt(v1.x * v1.x + v1.z * v1.z);
+        v2 = mkv<R>(-v1.z * inv_len, R(0), v1.x * inv_len);
     } else {
-        double inv_len = 1. / sqrt(v1.y * v1.y + v1.z * v1.z);
-        v2 = mk3(0., -v1.z * inv_len, v1.y * inv_len);
+        R inv_len = R(1) / r_sqrt(v1.y * v1.y + v1.z * v1.z);
+        v2 = mkv<R>(R(0), -v1.z * inv_len, v1.y * inv_len);
     }
-    v3 = cross3(v1, v2);
+    v3_ = cross3(v1, v2);
 }
 
-// Sphere.intersect for a full sphere, shape/sphere.py:125-157 (np.roots → closed form)
+// Sphere.intersect for a full sphere, shape/sphere.py:125-157 (np.roots → closed form).  Binary64 in every
+// variant: it takes a point and decides hit / miss.
 __device__ inline bool sphere_intersect(const pt_light &lt, const Ray &rw, double &thit, d3 &phit_obj) {
     d3 o = xf_point(lt.w2o, rw.o), d = xf_vec(lt.w2o, rw.d);
     double A = sqlen3(d);
@@ -820,31 +887,30 @@ __device__ inline d3 sphere_hit_normal(const pt_light &lt, d3 phit) {
     return nn;
 }
 
-struct LightSample {
-    d3 Li, wi;
-    double pdf;
-    Ray shadow;
+template <typename R> struct LightSampleT {
+    v3<R> Li, wi;
+    R pdf;
+    Ray shadow;                // a ray: binary64
 };
 
 // DiffuseAreaLight.sample_l (light/light.py:514-521) → Sphere.sample_p (shape/sphere.py:78-110),
-// Sphere.pdf_p (:112-123), VisibilityTester.set_segment (light/utility.py:34-42)
-__device__ inline void sphere_light_sample_l(const pt_light &lt, d3 p, double pEps, double u1, double u2,
-                                             LightSample &o) {
+// Sphere.pdf_p (:112-123), VisibilityTester.set_segment (light/utility.py:34-42).
+// R = float: the cone frame, the sampled direction and the pdf are binary32; the inside / outside decision, the
+// intersection with the sphere, the sampled point and the shadow segment are binary64.
+template <typename R>
+__device__ inline void sphere_light_sample_l(const pt_light &lt, d3 p, double pEps, R u1, R u2, LightSampleT<R> &o) {
     d3 ctr = mk3(lt.pos[0], lt.pos[1], lt.pos[2]);
-    d3 wc = normalize3(ctr - p);
-    d3 wcx, wcy;
-    coordinate_system(wc, wcx, wcy);
     d3 dcp = p - ctr;
     double sqd = dcp.x * dcp.x + dcp.y * dcp.y + dcp.z * dcp.z;
     bool inside = (sqd - lt.radius * lt.radius < PT_EPS);
     d3 ps, ns;
-    double pdf;
+    R pdf;
     if (inside) {
-        // Sphere.sample AS WRITTEN, sphere.py:43-60 (Q7)
+        // Sphere.sample AS WRITTEN, sphere.py:43-60 (Q7).  Rare (a vertex inside the light): binary64 throughout.
         const double phiMax = 2. * PT_PI, thetaMin = PT_PI, thetaMax = 0.;
-        double z = 1. - 2. * u1;
+        double z = 1. - 2. * (double)u1;
         double r = sqrt(max0(1. - z * z));
-        double ph = 2. * PT_PI * u2;
+        double ph = 2. * PT_PI * (double)u2;
         d3 v = mk3(r * cos(ph), r * sin(ph), z);
         double sth = acos(clipd(v.z, -1., 1.));
         double phi = sth * phiMax * PT_INV_2PI;
@@ -856,16 +922,19 @@ __device__ inline void sphere_light_sample_l(const pt_light &lt, d3 p, double pE
         if (lt.ro) ns = ns * -1.;
         ps = xf_point(lt.o2w, v);
     } else {
-        double st_max_sq = lt.radius * lt.radius / sqd;
-        double ct_max = sqrt(max0(1. - st_max_sq));
+        v3<R> wc = cvt3<R>(normalize3(ctr - p));
+        v3<R> wcx, wcy;
+        coordinate_system(wc, wcx, wcy);
+        R st_max_sq = (R)(lt.radius * lt.radius / sqd);
+        R ct_max = r_sqrt(max0(R(1) - st_max_sq));
         // uniform_sample_cone with a basis, montecarlo/utility.py:222-226
-        double ct = (1. - u1) * ct_max + u1 * 1.;
-        double st = sqrt(1. - ct * ct);
-        double phi = u2 * 2. * PT_PI, sphi, cphi;
-        sincos(phi, &sphi, &cphi);
-        d3 dir = ((wcx * (cphi * st)) + (wcy * (sphi * st))) + (wc * ct);
+        R ct = (R(1) - u1) * ct_max + u1 * R(1);
+        R st = r_sqrt(R(1) - ct * ct);
+        R phi = u2 * R(2) * R(PT_PI), sphi, cphi;
+        r_sincos(phi, &sphi, &cphi);
+        v3<R> dir = ((wcx * (cphi * st)) + (wcy * (sphi * st))) + (wc * ct);
         Ray r;
-        r.o = p; r.d = dir; r.mint = PT_EPS; r.maxt = __builtin_inf();
+        r.o = p; r.d = cvt3<double>(dir); r.mint = PT_EPS; r.maxt = __builtin_inf();
         double thit;
         d3 dummy;
         if (!sphere_intersect(lt, r, thit, dummy)) thit = dot3(ctr - p, normalize3(r.d));
@@ -873,29 +942,30 @@ __device__ inline void sphere_light_sample_l(const pt_light &lt, d3 p, double pE
         ns = normalize3(ps - ctr);
         if (lt.ro) ns = ns * -1.;
     }
-    d3 wi = normalize3(ps - p);
+    d3 wi_d = normalize3(ps - p);
     if (inside) {
         // Shape.pdf_p, shape/__init__.py:122-140
         Ray r;
-        r.o = p; r.d = wi; r.mint = PT_EPS; r.maxt = __builtin_inf();
+        r.o = p; r.d = wi_d; r.mint = PT_EPS; r.maxt = __builtin_inf();
         double thit;
         d3 ph;
-        if (!sphere_intersect(lt, r, thit, ph)) pdf = 0.;
+        if (!sphere_intersect(lt, r, thit, ph)) pdf = R(0);
         else {
             d3 nn = sphere_hit_normal(lt, ph);
             d3 hitp = r.o + r.d * thit;
             double area = (2. * PT_PI) * lt.radius * (lt.radius - (-lt.radius));
-            pdf = sqlen3(p - hitp) / (fabs(dot3(nn, -wi)) * area);
+            pdf = (R)(sqlen3(p - hitp) / (fabs(dot3(nn, -wi_d)) * area));
         }
     } else {
+        // 1 - cos(theta_max) cancels (a light of radius 3 at distance 60: 1 - 0.99875): binary64 in every variant
         double st_max_sq = lt.radius * lt.radius / sqd;
         double ct_max = sqrt(max0(1. - st_max_sq));
-        pdf = 1. / (2. * PT_PI * (1. - ct_max));
+        pdf = (R)(1. / (2. * PT_PI * (1. - ct_max)));
     }
     // DiffuseAreaLight.l, light.py:507-508
-    if (dot3(ns, -wi) > 0.) o.Li = mk3(lt.emit[0], lt.emit[1], lt.emit[2]);
-    else o.Li = mk3(0, 0, 0);
-    o.wi = wi;
+    if (dot3(ns, -wi_d) > 0.) o.Li = mkv<R>((R)lt.emit[0], (R)lt.emit[1], (R)lt.emit[2]);
+    else o.Li = mkv<R>(R(0), R(0), R(0));
+    o.wi = cvt3<R>(wi_d);
     o.pdf = pdf;
     double dist = len3(p - ps);
     o.shadow.o = p;
@@ -905,23 +975,26 @@ __device__ inline void sphere_light_sample_l(const pt_light &lt, d3 p, double pE
 }
 
 // SpotLight.sample_l (light.py:190-196; divides by the falloff, no 1/r², Q9) and
-// PointLight.sample_l (light.py:129-135)
-__device__ inline void delta_light_sample_l(const pt_light &lt, d3 p, double pEps, LightSample &o) {
+// PointLight.sample_l (light.py:129-135).  Points and the cone decision in binary64.
+template <typename R>
+__device__ inline void delta_light_sample_l(const pt_light &lt, d3 p, double pEps, LightSampleT<R> &o) {
     d3 pos = mk3(lt.pos[0], lt.pos[1], lt.pos[2]);
     d3 wi = normalize3(pos - p);
     d3 I = mk3(lt.emit[0], lt.emit[1], lt.emit[2]);
+    d3 Li;
     if (lt.kind == PT_LIGHT_SPOT) {
         d3 wl = normalize3(xf_vec(lt.w2o, -wi));
         double ct = wl.z, fo;
         if (ct < lt.cos_width) fo = 0.;
         else if (ct > lt.cos_falloff) fo = 1.;
         else { double d = (ct - lt.cos_width) / (lt.cos_falloff - lt.cos_width); fo = d * d * d * d; }
-        o.Li = I / fo;
+        Li = I / fo;
     } else {
-        o.Li = I / sqlen3(pos - p);
+        Li = I / sqlen3(pos - p);
     }
-    o.wi = wi;
-    o.pdf = 1.;
+    o.Li = cvt3<R>(Li);
+    o.wi = cvt3<R>(wi);
+    o.pdf = R(1);
     double dist = len3(p - pos);
     o.shadow.o = p;
     o.shadow.d = (pos - p) / dist;
@@ -930,9 +1003,9 @@ __device__ inline void delta_light_sample_l(const pt_light &lt, d3 p, double pEp
 }
 
 // util.is_black on an array: all |c| < EPS (utility/utility.py:119-124)
-__device__ __forceinline__ bool util_is_black(d3 s) { return fabs(s.x) < PT_EPS && fabs(s.y) < PT_EPS && fabs(s.z) < PT_EPS; }
+template <typename R> __device__ __forceinline__ bool util_is_black(v3<R> s) { return r_abs(s.x) < R(PT_EPS) && r_abs(s.y) < R(PT_EPS) && r_abs(s.z) < R(PT_EPS); }
 // CoefficientSpectrum.is_black: all c < EPS (spectral/spectrum.py:182-187)
-__device__ __forceinline__ bool spec_is_black(d3 s) { return s.x < PT_EPS && s.y < PT_EPS && s.z < PT_EPS; }
+template <typename R> __device__ __forceinline__ bool spec_is_black(v3<R> s) { return s.x < R(PT_EPS) && s.y < R(PT_EPS) && s.z < R(PT_EPS); }
 // RGBSpectrum.y, spectrum.py:587-589
 __device__ __forceinline__ double spec_y(d3 s) { return (0.212671 * s.x + 0.715160 * s.y) + 0.072169 * s.z; }
 

@@ -145,9 +145,9 @@ hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid,
 hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, int gshift,
                             const Queue &q, const PathState &st, unsigned long long *counters);
 hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, const HitList &hl);
-hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,
-                           int level, const Queue &qin, const HitList &hl, const Queue &qout, const ShadowQueue &sh,
-                           const PathState &st);
+hipError_t pt_launch_shade(int kind, bool f32, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc,
+                           long base, int level, const Queue &qin, const HitList &hl, const Queue &qout,
+                           const ShadowQueue &sh, const PathState &st);
 hipError_t pt_launch_splat(hipStream_t stream, const RenderConst *rc, const pt_tile &tile, const pt_film_desc &fm,
                            long base, int nb, const PathState &st, double *film, double *sample_L,
                            unsigned long long *counters);

@@ -914,24 +914,24 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
 
 // estimate_direct AS IT EXECUTES (integrator/utility.py:203-257; only the light-sampling half
 // contributes, Q3).  Returns true if a shadow ray must be traced; c = contribution if unoccluded.
-template <bool EXT>
-__device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, const Vertex &vx, d3 wo, double u0,
-                                       double u1, Ray &shadow, d3 &c) {
+template <bool EXT, typename R>
+__device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, const VertexT<R> &vx, v3<R> wo, R u0,
+                                       R u1, Ray &shadow, d3 &c) {
     const unsigned flags = BDF_ALL & ~BDF_SPECULAR;
-    LightSample ls;
-    if (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) sphere_light_sample_l(lt, vx.p, vx.rEps, u0, u1, ls);
-    else delta_light_sample_l(lt, vx.p, vx.rEps, ls);
-    if (!(ls.pdf > 0. && !util_is_black(ls.Li))) return false;
-    double bp = 0.;
-    d3 f = (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) ? bsdf_f_pdf<EXT>(vx, wo, ls.wi, flags, bp) : bsdf_f<EXT>(vx, wo, ls.wi, flags);
+    LightSampleT<R> ls;
+    if (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) sphere_light_sample_l<R>(lt, vx.p, vx.rEps, u0, u1, ls);
+    else delta_light_sample_l<R>(lt, vx.p, vx.rEps, ls);
+    if (!(ls.pdf > R(0) && !util_is_black(ls.Li))) return false;
+    R bp = R(0);
+    v3<R> f = (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) ? bsdf_f_pdf<EXT>(vx, wo, ls.wi, flags, bp) : bsdf_f<EXT>(vx, wo, ls.wi, flags);
     if (util_is_black(f)) return false;
-    double adot = fabs(dot3(ls.wi, vx.nn));
+    R adot = r_abs(dot3(ls.wi, vx.nn));
     if (lt.kind != PT_LIGHT_DIFFUSE_SPHERE) {
-        c = (f * ls.Li) * (adot / ls.pdf);
+        c = cvt3<double>((f * ls.Li) * (adot / ls.pdf));
     } else {
-        double ff = 1 * ls.pdf, g = 1 * bp;
-        double weight = ff * ff / (ff * ff + g * g);   // power_heuristic, montecarlo/utility.py:33-42
-        c = (f * ls.Li) * (adot * weight / ls.pdf);
+        R ff = 1 * ls.pdf, g = 1 * bp;
+        R weight = ff * ff / (ff * ff + g * g);   // power_heuristic, montecarlo/utility.py:33-42
+        c = cvt3<double>((f * ls.Li) * (adot * weight / ls.pdf));
     }
     shadow = ls.shadow;
     return true;
@@ -939,16 +939,16 @@ __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, con
 
 // One light of WhittedIntegrator.li (integrator/surface/whitted.py:44-53): no MIS, bsdf.f with the
 // default flags, Spectrum.is_black tests.  Returns true if a shadow ray must be traced.
-template <bool EXT>
-__device__ inline bool estimate_whitted(const DScene &sc, const pt_light &lt, const Vertex &vx, d3 wo, double u0,
-                                        double u1, Ray &shadow, d3 &c) {
-    LightSample ls;
-    if (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) sphere_light_sample_l(lt, vx.p, vx.rEps, u0, u1, ls);
-    else delta_light_sample_l(lt, vx.p, vx.rEps, ls);
-    if (spec_is_black(ls.Li) || ls.pdf == 0.) return false;
-    d3 f = bsdf_f<EXT>(vx, wo, ls.wi, BDF_ALL);
+template <bool EXT, typename R>
+__device__ inline bool estimate_whitted(const DScene &sc, const pt_light &lt, const VertexT<R> &vx, v3<R> wo, R u0,
+                                        R u1, Ray &shadow, d3 &c) {
+    LightSampleT<R> ls;
+    if (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) sphere_light_sample_l<R>(lt, vx.p, vx.rEps, u0, u1, ls);
+    else delta_light_sample_l<R>(lt, vx.p, vx.rEps, ls);
+    if (spec_is_black(ls.Li) || ls.pdf == R(0)) return false;
+    v3<R> f = bsdf_f<EXT>(vx, wo, ls.wi, BDF_ALL);
     if (spec_is_black(f)) return false;
-    c = (((f * ls.Li) * fabs(dot3(ls.wi, vx.nn))) * 1.) / ls.pdf;   // x transmittance (= 1) / pdf
+    c = cvt3<double>((((f * ls.Li) * r_abs(dot3(ls.wi, vx.nn))) * R(1)) / ls.pdf);   // x transmittance (= 1) / pdf
     shadow = ls.shadow;
     return true;
 }
@@ -976,13 +976,17 @@ __device__ __forceinline__ void push_shadow(const ShadowQueue &sh, int region, b
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2
 #endif
+#ifndef PT_SHADE_WAVES_F32
+#define PT_SHADE_WAVES_F32 3      // measured: 2 / 3 / 4 waves per SIMD -> shade 24.9 / 23.9 / 26.2 ms (overlapped timing)
+#endif
 #define PT_SHADE_LDS_MATS 64      // 34 KB
 #define PT_SHADE_LDS_LIGHTS 16    // 4.5 KB (pt_scene_upload's limit)
 static_assert(sizeof(pt_material) % 8 == 0 && sizeof(pt_light) % 8 == 0, "copied to LDS in 8-byte words");
 // EXT (compile-time, so that plain scenes run the kernel unchanged): 0 = plain; 1 = the scene has textured lobes or
 // mesh uvs; 2 = it has measured BRDF lobes as well or instead
-template <int KIND, int EXT>
-__global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
+// R: binary64 (parity; the reference's arithmetic) or binary32 (production only: BSDF / light arithmetic, pt_device.h)
+template <int KIND, int EXT, typename R>
+__global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT_SHADE_WAVES)) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
                                                     int level, Queue qin, HitList hl, Queue qout, ShadowQueue sh,
                                                     PathState st) {
     const RenderConst &rc = *rcp;
@@ -1037,21 +1041,23 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
         if (live) T = mk3(st.T[slot], st.T[P + slot], st.T[2 * P + slot]);
         const bool hit = live && prim >= 0;
         Ray ray;
-        Vertex vx;
-        d3 wo = mk3(0, 0, 0);
+        VertexT<R> vx;
+        v3<R> wo = mkv<R>(R(0), R(0), R(0));
         SampleSrc ss;
         ss.row = nullptr; ss.msid = 0;
         if (hit) {
             ray.o = mk3(qin.rays[i], qin.rays[S + i], qin.rays[2 * S + i]);
             ray.d = mk3(qin.rays[3 * S + i], qin.rays[4 * S + i], qin.rays[5 * S + i]);
-            make_vertex<EXT != 0>(sc, ray, prim, qin.t[i], vx);
-            vx.mat = mats_p + (vx.mat - sc.mats);
-            vx.brdf = brdf;
-            vx.brdf_in_lds = EXT == 2 && sc.brdf_lds_bytes > 0;
-            vx.hits = hits;
+            Vertex vd;                                   // the vertex and its frame are built in binary64
+            make_vertex<EXT != 0>(sc, ray, prim, qin.t[i], vd);
+            vd.mat = mats_p + (vd.mat - sc.mats);
+            vd.brdf = brdf;
+            vd.brdf_in_lds = EXT == 2 && sc.brdf_lds_bytes > 0;
+            vd.hits = hits;
             if (EXT != 0 && sc.textures)
-                apply_textures(sc, vx, prim, qin.b1[i], qin.b2[i], sc.tex_scratch + ((size_t)blockIdx.x * PT_BLOCK + threadIdx.x));
-            wo = -ray.d;
+                apply_textures(sc, vd, prim, qin.b1[i], qin.b2[i], sc.tex_scratch + ((size_t)blockIdx.x * PT_BLOCK + threadIdx.x));
+            vx = vertex_as<R>(vd);
+            wo = cvt3<R>(-ray.d);
             int px, py, si;
             uint32_t sid;
             tile_decode(rc, base + slot, px, py, si, sid);
@@ -1068,8 +1074,8 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                 Ray sr;
                 d3 c = mk3(0, 0, 0);
                 if (hit) {
-                    need = estimate_whitted<EXT == 2>(sc, lights_p[li], vx, wo, hash_uniform(ss.msid, k),
-                                            hash_uniform(ss.msid, k + 1), sr, c);
+                    need = estimate_whitted<EXT == 2, R>(sc, lights_p[li], vx, wo, (R)hash_uniform(ss.msid, k),
+                                                         (R)hash_uniform(ss.msid, k + 1), sr, c);
                     c = T * c;
                 }
                 push_shadow(sh, region, need, sr, c, slot);
@@ -1087,7 +1093,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                     if (hit) {
                         double u0, u1;
                         direct_light_uv(ss, off, ns, j, perm, u0, u1);
-                        need = estimate_direct<EXT == 2>(sc, lights_p[li], vx, wo, u0, u1, sr, c);
+                        need = estimate_direct<EXT == 2, R>(sc, lights_p[li], vx, wo, (R)u0, (R)u1, sr, c);
                         c = T * (c / (double)ns);
                     }
                     push_shadow(sh, region, need, sr, c, slot);
@@ -1097,13 +1103,13 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
         if (KIND != PT_INTEG_PATH) {
             // specular_reflect, integrator/utility.py:120-155 (shared by Direct and Whitted)
             if (hit && (level + 1 < rc.ig.max_depth)) {
-                d3 wi, f;
-                double pdf = bsdf_sample_f<EXT == 2>(vx, wo, 0., 0., 0., BDF_REFLECTION | BDF_SPECULAR, wi, f);
-                double adot = fabs(dot3(wi, vx.nn));
-                if (pdf > 0. && !util_is_black(f) && adot != 0.) {
-                    T = T * ((f * adot) / pdf);
+                v3<R> wi, f;
+                R pdf = bsdf_sample_f<EXT == 2, R>(vx, wo, R(0), R(0), 0., BDF_REFLECTION | BDF_SPECULAR, wi, f);
+                R adot = r_abs(dot3(wi, vx.nn));
+                if (pdf > R(0) && !util_is_black(f) && adot != R(0)) {
+                    T = T * cvt3<double>((f * adot) / pdf);
                     cont = true;
-                    nray.o = vx.p; nray.d = wi; nray.mint = vx.rEps; nray.maxt = __builtin_inf();
+                    nray.o = vx.p; nray.d = cvt3<double>(wi); nray.mint = vx.rEps; nray.maxt = __builtin_inf();
                 }
             }
         } else {
@@ -1130,7 +1136,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                 }
                 int ln = (int)floor(ulnum * sc.n_lights);
                 if (ln > sc.n_lights - 1) ln = sc.n_lights - 1;
-                need = estimate_direct<EXT == 2>(sc, lights_p[ln], vx, wo, u0, u1, sr, c);
+                need = estimate_direct<EXT == 2, R>(sc, lights_p[ln], vx, wo, (R)u0, (R)u1, sr, c);
                 c = T * (c * (double)sc.n_lights);
             }
             push_shadow(sh, region, need, sr, c, slot);
@@ -1146,10 +1152,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                     u1 = hash_uniform(ss.msid, kk + 1);
                     uc = hash_uniform(ss.msid, kk + 2);
                 }
-                d3 wi, f;
-                double pdf = bsdf_sample_f<EXT == 2>(vx, wo, u0, u1, uc, BDF_ALL, wi, f);
-                if (!(spec_is_black(f) || pdf == 0.)) {
-                    T = T * ((f * fabs(dot3(wi, vx.nn))) / pdf);
+                v3<R> wi, f;
+                R pdf = bsdf_sample_f<EXT == 2, R>(vx, wo, (R)u0, (R)u1, uc, BDF_ALL, wi, f);
+                if (!(spec_is_black(f) || pdf == R(0))) {
+                    T = T * cvt3<double>((f * r_abs(dot3(wi, vx.nn))) / pdf);
                     cont = true;
                     if (level > 3) {
                         double ty = spec_y(T);
@@ -1159,7 +1165,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene sc, c
                         T = T / cont_prob;
                     }
                     if (level == rc.ig.max_depth) cont = false;
-                    nray.o = vx.p; nray.d = wi; nray.mint = vx.rEps; nray.maxt = __builtin_inf();
+                    nray.o = vx.p; nray.d = cvt3<double>(wi); nray.mint = vx.rEps; nray.maxt = __builtin_inf();
                 }
             }
         }
@@ -1218,26 +1224,34 @@ hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, con
     return hipGetLastError();
 }
 
-hipError_t pt_launch_shade(int kind, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc, long base,
-                           int level, const Queue &qin, const HitList &hl, const Queue &qout, const ShadowQueue &sh,
-                           const PathState &st) {
+hipError_t pt_launch_shade(int kind, bool f32, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc,
+                           long base, int level, const Queue &qin, const HitList &hl, const Queue &qout,
+                           const ShadowQueue &sh, const PathState &st) {
     grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
     // the measured variants take up to PT_MEAS_LDS_MAX of dynamic LDS (hit lists + table blob): beyond the 64 KB a
     // kernel gets by default, so the limit is raised once per device and kernel
-    static bool attr_set[PT_MAX_DEVICES][3];
+    static bool attr_set[PT_MAX_DEVICES][3][2];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
-    if (sc.brdf != nullptr && (kind == PT_INTEG_DIRECT || kind == PT_INTEG_PATH || kind == PT_INTEG_WHITTED) && !attr_set[dev][kind]) {
-        const void *fn = kind == PT_INTEG_DIRECT ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_DIRECT, 2>)
-                       : kind == PT_INTEG_WHITTED ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_WHITTED, 2>)
-                                                  : reinterpret_cast<const void *>(&k_shade<PT_INTEG_PATH, 2>);
+    if (sc.brdf != nullptr && (kind == PT_INTEG_DIRECT || kind == PT_INTEG_PATH || kind == PT_INTEG_WHITTED) &&
+        !attr_set[dev][kind][f32 ? 1 : 0]) {
+        const void *fn;
+        if (f32)
+            fn = kind == PT_INTEG_DIRECT ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_DIRECT, 2, float>)
+               : kind == PT_INTEG_WHITTED ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_WHITTED, 2, float>)
+                                          : reinterpret_cast<const void *>(&k_shade<PT_INTEG_PATH, 2, float>);
+        else
+            fn = kind == PT_INTEG_DIRECT ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_DIRECT, 2, double>)
+               : kind == PT_INTEG_WHITTED ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_WHITTED, 2, double>)
+                                          : reinterpret_cast<const void *>(&k_shade<PT_INTEG_PATH, 2, double>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_MEAS_LDS_MAX);
         if (e != hipSuccess) return e;
-        attr_set[dev][kind] = true;
+        attr_set[dev][kind][f32 ? 1 : 0] = true;
     }
-#define PT_SHADE(K, T) hipLaunchKernelGGL((k_shade<K, T>), dim3(grid), dim3(PT_BLOCK), (T) == 2 ? (size_t)sc.brdf_lds_bytes + PT_MEAS_HITS * PT_BLOCK * sizeof(int) : 0, stream, sc, rc, base, level, qin, hl, qout, sh, st)
+#define PT_SHADE(K, T, R) hipLaunchKernelGGL((k_shade<K, T, R>), dim3(grid), dim3(PT_BLOCK), (T) == 2 ? (size_t)sc.brdf_lds_bytes + PT_MEAS_HITS * PT_BLOCK * sizeof(int) : 0, stream, sc, rc, base, level, qin, hl, qout, sh, st)
     const int ext = sc.brdf != nullptr ? 2 : ((sc.textures != nullptr || sc.tri_uv != nullptr) ? 1 : 0);
-#define PT_SHADE_EXT(K) do { if (ext == 2) PT_SHADE(K, 2); else if (ext == 1) PT_SHADE(K, 1); else PT_SHADE(K, 0); } while (0)
+#define PT_SHADE_EXT(K) do { if (f32) { if (ext == 2) PT_SHADE(K, 2, float); else if (ext == 1) PT_SHADE(K, 1, float); else PT_SHADE(K, 0, float); } \
+                             else { if (ext == 2) PT_SHADE(K, 2, double); else if (ext == 1) PT_SHADE(K, 1, double); else PT_SHADE(K, 0, double); } } while (0)
     if (kind == PT_INTEG_DIRECT) PT_SHADE_EXT(PT_INTEG_DIRECT);
     else if (kind == PT_INTEG_WHITTED) PT_SHADE_EXT(PT_INTEG_WHITTED);
     else PT_SHADE_EXT(PT_INTEG_PATH);

@@ -584,20 +584,21 @@ def sampler_desc_from_object(sampler, seed=0):
                         sampler.xSamples, sampler.ySamples, sampler.jitter, seed)
 
 
-def integrator_desc(kind, max_depth=5, pretest=False):
+def integrator_desc(kind, max_depth=5, pretest=False, shade_f32=False):
     i = A.pt_integrator_desc()
     i.kind, i.max_depth, i.pretest = int(kind), int(max_depth), int(bool(pretest))
+    i.shade_f32 = int(bool(shade_f32))          # production streams only (include/pytracer_hip.h)
     return i
 
 
-def integrator_desc_from_object(integ, pretest=False):
+def integrator_desc_from_object(integ, pretest=False, shade_f32=False):
     nm = type(integ).__name__
     if nm == 'DirectLightingIntegrator':
-        return integrator_desc(A.PT_INTEG_DIRECT, integ.max_depth, pretest)
+        return integrator_desc(A.PT_INTEG_DIRECT, integ.max_depth, pretest, shade_f32)
     if nm == 'PathIntegrator':
-        return integrator_desc(A.PT_INTEG_PATH, integ.max_depth, pretest)
+        return integrator_desc(A.PT_INTEG_PATH, integ.max_depth, pretest, shade_f32)
     if nm == 'WhittedIntegrator':
-        return integrator_desc(A.PT_INTEG_WHITTED, integ.max_depth, pretest)
+        return integrator_desc(A.PT_INTEG_WHITTED, integ.max_depth, pretest, shade_f32)
     raise NotImplementedError('integrator %s is outside the supported hot path' % nm)
 
 

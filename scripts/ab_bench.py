@@ -50,26 +50,27 @@ def main():
     arms = []
     for e in args.env or ['']:
         kv = dict(x.split('=') for x in e.split(',') if x)
+        f32 = kv.pop('F32', '0') == '1'           # pseudo-variable: this arm renders with shade_f32 = 1
         os.environ.update(kv)
         c = Context(0)
         c.upload(flat)
         c.set_profiling(True)
         for k in kv:
             del os.environ[k]
-        arms.append((e, c))
+        arms.append((e, c, f32))
     cam, film = (workloads.c4_camera_film(xres, yres) if args.workload == 'c4'
                  else host.head_mesh_camera_film(xres, yres))
     kind = A.PT_INTEG_PATH if args.integrator == 'path' else A.PT_INTEG_DIRECT
-    integ = pa.integrator_desc(kind, 5, False)
+    integs = {False: pa.integrator_desc(kind, 5, False), True: pa.integrator_desc(kind, 5, False, shade_f32=True)}
     smp = pa.sampler_desc(0, xres, 0, yres, args.spp, ys, True, 0)
     tile = pa.tile_desc(0, xres, 0, yres, 0, args.spp * ys)
     acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
     sums = {}
     for rnd in range(args.rounds + 1):
-        for name, c in arms:
+        for name, c, f32 in arms:
             acc.zero_()
             st = A.pt_stats()
-            c.render(cam, film, smp, integ, tile, acc, stats=st)
+            c.render(cam, film, smp, integs[f32], tile, acc, stats=st)
             torch.cuda.synchronize()
             if rnd == 0:
                 sums[name] = float(acc.sum().item())
