@@ -291,16 +291,25 @@ def main():
         del accx
 
     if rank == 0:
-        # dominant kernel: whichever of the two traversal kernels took more time
-        n_any, n_clo = st.rays_any, st.rays_closest
-        nv_any, nt_any = st.node_visits_any, st.tri_tests_any
-        nv_clo, nt_clo = st.node_visits - nv_any, st.tri_tests - nt_any
-        cand = {
-            'k_trace<closest>': (st.ms_trace_closest, st.launches_trace_closest, algorithmic_bytes(n_clo, nv_clo, nt_clo),
-                                 n_clo, nv_clo, nt_clo),
-            'k_trace<any>': (st.ms_trace_any, st.launches_trace_any, algorithmic_bytes(n_any, nv_any, nt_any),
-                             n_any, nv_any, nt_any),
-        }
+        # Dominant kernel: whichever of the two traversal kernels takes more time BY ITSELF.  With the render's two
+        # streams (PT_OVERLAP, default) HIP-event durations inside the timed region include the time a kernel spends
+        # queued behind, or sharing CUs with, the other stream's kernels (the any-hit launches read 3x "longer" than
+        # alone while the step gets shorter), so they cannot price a kernel against a roofline.  The roofline is
+        # therefore taken from the two steps run right after the timed region on a second context with the overlap off
+        # (`excl`: same process, same inputs, same launches — these durations are what rocprofv3 --kernel-trace reports
+        # for the command, profiles/); the timed region's own event figures are kept under `timed_region`.
+        def per_kernel(stt, steps):
+            n_any, n_clo = stt.rays_any, stt.rays_closest
+            nv_any, nt_any = stt.node_visits_any, stt.tri_tests_any
+            nv_clo, nt_clo = stt.node_visits - nv_any, stt.tri_tests - nt_any
+            return {
+                'k_trace<closest>': (stt.ms_trace_closest, stt.launches_trace_closest,
+                                     algorithmic_bytes(n_clo, nv_clo, nt_clo), n_clo, nv_clo, nt_clo),
+                'k_trace<any>': (stt.ms_trace_any, stt.launches_trace_any, algorithmic_bytes(n_any, nv_any, nt_any),
+                                 n_any, nv_any, nt_any),
+            }
+        src, src_steps = (excl, 2) if excl is not None else (st, args.steps)
+        cand = per_kernel(src, src_steps)
         name = max(cand, key=lambda k: cand[k][0])
         ms, launches, abytes, nr, nv, nt = cand[name]
         achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -326,27 +335,28 @@ def main():
                 # what the HBM actually carries: the tree is cache-resident, so this is far below `frac`, which prices
                 # every node / triangle byte as if streamed.  The real limiter is named here.
                 'hbm_traffic_frac': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
-                'limiter': 'vector-memory (L1/TA) line rate and dependent-fetch latency of per-lane node loads; '
+                'limiter': 'vector-memory (L1/TA) request rate and dependent-fetch latency of per-lane node loads; '
                            'HBM carries the ray/hit streams only (DESIGN.md section 5-6)',
                 'kernel': name,
                 'kernel_note': 'closest-hit launches run k_trace_meta<false> (child words in LDS) on trees of up to ~7900 '
-                               'nodes, k_trace<STACK,false> otherwise; profiles/ lists the symbol under full_name',
-                'launches': int(launches), 'avg_launch_ms': ms / max(launches, 1),
+                               'nodes, k_trace_pair<false> (children-pair records) on larger ones; profiles/ lists the '
+                               'symbol under full_name',
+                'measured': ('2 steps after the timed region on a second context with PT_OVERLAP=0 (the kernel alone on '
+                             'the GPU)' if excl is not None else 'HIP events over the timed region (single stream)'),
+                'launches': int(launches), 'avg_launch_ms': avg_ms,
                 'algorithmic_bytes_per_launch': abytes / max(launches, 1),
                 'rays': int(nr), 'node_visits_per_ray': nv / max(nr, 1), 'tri_tests_per_ray': nt / max(nr, 1),
                 'kernel_Mrays_per_s': nr / (ms * 1e-3) / 1e6 if ms > 0 else 0.0,
-                'stage_ms_per_step': {k: v / args.steps for k, v in st.timing().items()}}
+                'stage_ms_per_step': {k: v / src_steps for k, v in src.timing().items()}}
         if excl is not None:
-            ex_ms, ex_launches = ((excl.ms_trace_closest, excl.launches_trace_closest) if name == 'k_trace<closest>'
-                                  else (excl.ms_trace_any, excl.launches_trace_any))
-            ex_bytes = abytes / max(args.steps, 1) * 2            # the same launches, two steps
-            roof['concurrency'] = ('timed region: any-hit traces run on a second stream beside closest-hit traces and '
-                                   'shading, so `achieved` / `frac` price this kernel while it shares the GPU; '
-                                   '`exclusive` = the same launches with the overlap off (2 extra steps, untimed)')
-            roof['exclusive'] = {'achieved': ex_bytes / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else 0.0,
-                                 'frac': (ex_bytes / (ex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ex_ms > 0 else 0.0,
-                                 'avg_launch_ms': ex_ms / max(ex_launches, 1),
-                                 'stage_ms_per_step': {k: v / 2 for k, v in excl.timing().items()}}
+            t_ms, t_launches, t_bytes = per_kernel(st, args.steps)[name][:3]
+            roof['timed_region'] = {
+                'note': 'HIP events around the same launches inside the timed region, where the any-hit traces run on a '
+                        'second stream beside closest-hit traces and shading: durations include queueing / sharing',
+                'achieved': t_bytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0,
+                'frac': (t_bytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ms > 0 else 0.0,
+                'avg_launch_ms': t_ms / max(t_launches, 1),
+                'stage_ms_per_step': {k: v / args.steps for k, v in st.timing().items()}}
         out = {
             'metric': 'Mrays/s', 'value': rays_total / dt / 1e6, 'unit': 'Mrays/s',
             'samples_per_s': samples_total / dt,

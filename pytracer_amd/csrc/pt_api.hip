@@ -994,7 +994,9 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         // shading do not depend on it (its only output is atomic adds into L).  With PT_OVERLAP (default) it runs on
         // the context's second stream beside them: the sparse deep-bounce launches no longer leave the machine idle
         // in their tails.  Shadow queues alternate, so shade(k+2) waits for trace_any(k).
-        const bool ovl = c->overlap != 0;
+        // Not with measured BRDF lobes (unless PT_OVERLAP=2): that shade kernel needs its two 78 KB-LDS workgroups per
+        // CU, and an any-hit kernel resident beside it costs more than the filled tails give (C5: 371 vs 395 ms).
+        const bool ovl = c->overlap != 0 && (c->overlap >= 2 || c->sc.brdf == nullptr);
         bool any_pending[2] = {false, false};
         for (int level = 0; level < levels; level++) {
             Queue &qin = c->q[cur], &qout = c->q[cur ^ 1];

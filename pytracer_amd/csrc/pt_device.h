@@ -528,7 +528,7 @@ __device__ __forceinline__ void measured_scan(typename MeasPtr<LDS>::G gp, typen
 // holds fewer than 3 samples), which gives the round kf the reference stops at by the same `d2 <= r*r` comparisons;
 // phase 2 scans ball kf once, lists its samples and weights them.
 template <bool LDS>
-__device__ inline d3 measured_f_as(const char *base_generic, int table, d3 wo, d3 wi, int *hits_generic) {
+__device__ __forceinline__ d3 measured_f_as(const char *base_generic, int table, d3 wo, d3 wi, int *hits_generic) {
     typedef MeasPtr<LDS> MP;
     const typename MP::C base = (typename MP::C)base_generic;
     const lds_int_ptr hits = (lds_int_ptr)hits_generic;
@@ -588,7 +588,7 @@ __device__ inline d3 measured_f_as(const char *base_generic, int table, d3 wo, d
     }
     return mk3(max0(v.x), max0(v.y), max0(v.z)) / sum_wt;   // v.clip() / sum_wt
 }
-__device__ inline d3 measured_f(const char *base, bool in_lds, int table, d3 wo, d3 wi, int *hits) {
+__device__ __forceinline__ d3 measured_f(const char *base, bool in_lds, int table, d3 wo, d3 wi, int *hits) {
     return in_lds ? measured_f_as<true>(base, table, wo, wi, hits) : measured_f_as<false>(base, table, wo, wi, hits);
 }
 

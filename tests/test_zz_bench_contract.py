@@ -26,6 +26,8 @@ def test_bench_json_contract():
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert r['achieved'] > 0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 'traffic' in r
+    # the roofline is priced on the kernel alone (overlap off, after the timed region); the overlapped events are kept beside it
+    assert 'PT_OVERLAP=0' in r['measured'] and r['timed_region']['frac'] > 0 and 'traffic_source' in r
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and c['unit'] == 'Mrays/s' and c['sample']
     assert c['all_cores']['cores'] >= 1 and c['all_cores']['value'] > 0
