@@ -43,6 +43,7 @@ struct pt_ctx {
     hipStream_t aux;         // second stream of a render (created with the context)
     hipEvent_t ev_shade[2], ev_any[2];   // shade(k) done -> aux may trace sh[k&1]; that trace done -> sh[k&1] may be refilled
     int overlap;             // PT_OVERLAP=0: everything on the caller's stream
+    bool any_pending[2];     // an any-hit trace recorded ev_any[k] on `aux` and nothing has waited for it yet
     int use_top;             // stage the top of the tree in LDS (k_trace_top): PT_TRACE_TOP=0 never, 1 always,
                              // unset = for trees beyond the L2 (>= 2^18 nodes = 16 MB).  Measured:
                              // head mesh 5.5 k nodes -5 %, head_loop 352 k nodes +5 %, 10^6-triangle soup +19 %
@@ -949,6 +950,13 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     int rc = ensure_workspace(c, batch, spv, gshift);
     if (rc != PT_OK) return rc;
 
+    // a previous pt_render that failed half-way may have left any-hit traces running on the second stream: nothing of
+    // this call may touch the queues before they are done
+    for (int k = 0; k < 2; k++)
+        if (c->any_pending[k]) {
+            HIPCHK(c, hipStreamWaitEvent(stream, c->ev_any[k], 0));
+            c->any_pending[k] = false;
+        }
     HIPCHK(c, hipMemcpyAsync(c->d_rc, &h, sizeof(h), hipMemcpyHostToDevice, stream));
     unsigned long long *cnt = nullptr;
     if (stats) {
@@ -997,7 +1005,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         // Not with measured BRDF lobes (unless PT_OVERLAP=2): that shade kernel needs its two 78 KB-LDS workgroups per
         // CU, and an any-hit kernel resident beside it costs more than the filled tails give (C5: 371 vs 395 ms).
         const bool ovl = c->overlap != 0 && (c->overlap >= 2 || c->sc.brdf == nullptr);
-        bool any_pending[2] = {false, false};
+        bool *any_pending = c->any_pending;
         for (int level = 0; level < levels; level++) {
             Queue &qin = c->q[cur], &qout = c->q[cur ^ 1];
             const int sb = ovl ? (level & 1) : 0;
@@ -1049,7 +1057,10 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             }
         }
         for (int k = 0; k < 2; k++)      // the film needs every shadow contribution
-            if (any_pending[k]) HIPCHK(c, hipStreamWaitEvent(stream, c->ev_any[k], 0));
+            if (any_pending[k]) {
+                HIPCHK(c, hipStreamWaitEvent(stream, c->ev_any[k], 0));
+                any_pending[k] = false;
+            }
         {
             StageTimer tm(c, stream, STAGE_SPLAT);
             HIPCHK(c, pt_launch_splat(stream, c->d_rc, *tile, *film, base, nb, c->st, film_accum, sample_L, cnt));

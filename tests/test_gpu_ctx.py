@@ -60,3 +60,38 @@ def test_entry_points_keep_the_callers_device():
     assert torch.cuda.current_device() == before
     ctx.close()
     assert torch.cuda.current_device() == before
+
+
+def test_two_contexts_on_one_device_render_concurrently(golden_dir):
+    """One process may hold several contexts (one per GPU of a node, or several on one GPU): two contexts on cuda:0
+    render the two interleaved-row shards of one image on two torch streams at the same time; the sum equals the
+    one-context render (per-device launch attributes, workspaces and the second render stream are per context)."""
+    import torch
+    from pytracer_amd import host
+    from pytracer_amd._lib import Context
+    from pytracer_amd.renderer import shard_tile
+    d = dict(np.load(os.path.join(golden_dir, 'head_mesh_scene.npz')))
+    flat = pa.flat_scene_from_npz(d)
+    res, xs = 256, 4
+    cam, film = host.head_mesh_camera_film(res, res)
+    smp = pa.sampler_desc(0, res, 0, res, xs, xs, True, 11)
+    integ = pa.integrator_desc(A.PT_INTEG_PATH, 5, False)
+    ctxs = [Context(0), Context(0)]
+    for c in ctxs:
+        c.upload(flat)
+    whole = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
+    s_whole = A.pt_stats()
+    ctxs[0].render(cam, film, smp, integ, shard_tile(smp, 0, 1), whole, stats=s_whole)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    accs = [torch.zeros_like(whole) for _ in range(2)]
+    torch.cuda.synchronize()
+    for r in range(2):                                      # stats=None: nothing synchronises, both renders are in flight
+        ctxs[r].render(cam, film, smp, integ, shard_tile(smp, r, 2, 'interleaved'), accs[r],
+                       stream=streams[r].cuda_stream)
+    torch.cuda.synchronize()
+    both = accs[0] + accs[1]
+    assert float((both - whole).abs().max()) <= 1e-12 * float(whole.abs().max())
+    assert float(accs[0].abs().sum()) > 0 and float(accs[1].abs().sum()) > 0
+    for c in ctxs:
+        c.close()
