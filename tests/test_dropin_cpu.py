@@ -114,6 +114,50 @@ print('OK')
     assert out.returncode == 0 and 'OK' in out.stdout, out.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference not present (GPU box)')
+def test_textured_fixture_inputs_are_reference_derived(golden_dir):
+    """The material / texture INPUTS of the textured fixtures are what the fixture generator reads off the live
+    reference objects by itself (tools/oracle/gen_fixtures.py texture_dump: no product code on that side), they
+    equal the committed fixture files, and the product's flattener (flatten.texture_record) gives the same records
+    for the same objects."""
+    import subprocess
+    code = r'''
+import sys, os, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gen_fixtures as G
+assert 'pytracer_amd' not in sys.modules, 'the fixture generator imports the product'
+dumps = {}
+for variant, fname in (('tex', 'texmini_path_24x24x4.npz'), ('tex2', 'tex2mini_path_24x24x4.npz'), ('uv', 'uvmini_path_24x24x4.npz')):
+    model = G.C4Mini(variant)
+    d = G.dump_scene(model.scene)
+    assert 'pytracer_amd' not in sys.modules
+    fx = dict(np.load(os.path.join(%r, fname)))
+    keys = sorted(k for k in d if k.startswith('mat') or k == 'n_materials')
+    assert keys == sorted(k for k in fx if k.startswith('mat') or k == 'n_materials'), (variant, keys)
+    assert any('_tex_' in k for k in keys)
+    for k in keys:
+        assert np.array_equal(np.asarray(d[k]), fx[k]), (variant, k, d[k], fx[k])
+    dumps[variant] = model
+from pytracer_amd import flatten as F
+n = 0
+for variant, model in dumps.items():
+    for pr in model.scene.aggregate.primitives:
+        for name in ('Kd', 'Ks', 'Kr', 'Kt'):
+            t = getattr(pr.material, name, None)
+            if t is None or G.is_surface_constant(t):
+                continue
+            a, b = G.texture_dump(t), F.texture_record(t)
+            assert a['kind'] == b['kind'] and a['mapping'] == b['mapping']
+            assert np.array_equal(a['m'], b['m']) and np.array_equal(a['v'], b['v'])
+            n += 1
+assert n > 0
+print('OK')
+''' % (os.path.join(ROOT, 'tools', 'oracle'), ROOT, golden_dir)
+    out = subprocess.run([sys.executable, '-W', 'ignore', '-c', code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+    assert out.returncode == 0 and 'OK' in out.stdout, out.stderr[-2000:]
+
+
 def test_shard_tile_partitions_exactly():
     smp = pa.sampler_desc(3, 67, 5, 50, 4, 2)
     for world in (1, 2, 3, 8):

@@ -72,14 +72,67 @@ def tex_value(t):
     return t.value if hasattr(t, 'value') else t(None)
 
 
+# Texture / mapping codes of include/pytracer_hip.h (pt_texture.kind / .mapping), restated here so that the fixture
+# INPUTS do not pass through the product's flattener (tests/test_dropin_cpu.py compares the two on live objects).
+TEX_KIND = {'Chekcerboard2DTexture': 0, 'Checkboard3DTexture': 1, 'BilerpTexture': 2, 'UVTexture': 3}
+MAP_KIND = {'UVMapping2D': 0, 'PlannarMapping2D': 1, 'SphericalMapping2D': 2, 'IdentityMapping3D': 3}
+SURFACE_CONSTANT = ('ConstantTexture', 'ScaleTexture', 'MixTexture')
+
+
+def is_surface_constant(t):
+    nm = type(t).__name__
+    if nm == 'ConstantTexture':
+        return True
+    if nm in ('ScaleTexture', 'MixTexture'):
+        kids = [t.tex1, t.tex2] + ([t.amt] if nm == 'MixTexture' else [])
+        return all(is_surface_constant(k) for k in kids)
+    return False
+
+
+def as_rgb(v):
+    v = np.asarray(v, np.float64)
+    return np.full(3, float(v)) if v.ndim == 0 else np.array(v, np.float64)
+
+
+def texture_dump(t):
+    """{'kind', 'mapping', 'm'[16], 'v'[4][3]} of a spatially varying spectrum texture, read off the reference object:
+    the values of constant children are the REFERENCE's own evaluation (t(None)), clipped as the materials clip what
+    they evaluate (material.py:131); the mapping's 16 doubles are its attributes in the order pt_texture documents."""
+    nm = type(t).__name__
+    v = np.zeros((4, 3))
+
+    def child(x):
+        assert is_surface_constant(x), 'children of %s must be constant over the surface' % nm
+        return np.clip(as_rgb(x(None)), 0., np.inf)
+    if nm in ('Chekcerboard2DTexture', 'Checkboard3DTexture'):
+        v[0], v[1] = child(t.tex1), child(t.tex2)
+    elif nm == 'BilerpTexture':
+        for k, c in enumerate((t.v00, t.v01, t.v10, t.v11)):
+            v[k] = as_rgb(c)
+    elif nm != 'UVTexture':
+        raise NotImplementedError(nm)
+    mp = t.mapping
+    mn = type(mp).__name__
+    m = np.zeros(16)
+    if mn == 'UVMapping2D':
+        m[:4] = (mp.su, mp.sv, mp.du, mp.dv)
+    elif mn == 'PlannarMapping2D':
+        m[0:3], m[3:6], m[6], m[7] = np.array(mp.vs, np.float64), np.array(mp.vt, np.float64), mp.ds, mp.dt
+    elif mn in ('SphericalMapping2D', 'IdentityMapping3D'):
+        m[:] = np.array(mp.w2t.m, np.float64).reshape(16)
+    else:
+        raise NotImplementedError(mn)
+    return dict(kind=TEX_KIND[nm], mapping=MAP_KIND[mn], m=m, v=v)
+
+
 def spec_param(t):
-    """A spectrum parameter: the value of a constant texture, or the record of a varying one."""
+    """A spectrum parameter: the value of a texture that is constant over the surface (the reference's own
+    evaluation of it), or the record of a varying one."""
     if type(t).__name__ == 'ConstantTexture':
         return np.array(t.value)
-    sys.path.insert(0, os.path.normpath(os.path.join(HERE, '..', '..')))
-    from pytracer_amd.flatten import _const, texture_record
-    c = _const(t)
-    return np.array(c) if c is not None else texture_record(t)
+    if is_surface_constant(t):
+        return np.array(t(None))
+    return texture_dump(t)
 
 
 def dump_scene(scene, camera=None):
