@@ -255,6 +255,7 @@ def main():
                              'stage_ms_per_step': {k: v / args.steps for k, v in stk.timing().items()}}
         # the reduce itself cannot be timed on one GPU: its on-device half (acc += other, 32 MiB f64) can
         other = torch.ones_like(acc)
+        acc.add_(other)                         # first use loads torch's kernel: not part of the figure
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(20):

@@ -24,6 +24,8 @@ struct pt_ctx {
     void *d_pairs;           // GPair records of the interior nodes (k_trace_pair)
     int n_pairs;
     int use_pair;            // PT_TRACE_PAIR: 0 never, 1 always, unset (-1) = by tree size (launch_trace)
+    int shade_dynamic;       // PT_SHADE_DYNAMIC: the same for k_shade's walk over the hit list
+    int trace_dynamic;       // PT_TRACE_DYNAMIC: 0 = static chunk assignment in the trace launches of a render, else (default) chunk cursors
     size_t brdf_bytes;
     int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
     int meta_stack;          // todo levels of k_trace_meta's LDS stacks (0: the tree's child words do not fit in LDS)
@@ -168,6 +170,10 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     CREATE_CHK(hipMalloc((void **)&c->d_counters, (PT_CNT_SHARDS * CNT_COUNT + 4) * sizeof(unsigned long long)));
     c->overlap = 1;
     if (const char *e = getenv("PT_OVERLAP")) c->overlap = atoi(e);
+    c->trace_dynamic = -1;
+    c->shade_dynamic = -1;
+    if (const char *e = getenv("PT_SHADE_DYNAMIC")) c->shade_dynamic = atoi(e);
+    if (const char *e = getenv("PT_TRACE_DYNAMIC")) c->trace_dynamic = atoi(e);
     CREATE_CHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) {
         CREATE_CHK(hipEventCreateWithFlags(&c->ev_shade[k], hipEventDisableTiming));
@@ -970,12 +976,17 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     else levels = c->has_spec_reflect ? std::max(ig->max_depth, 1) : 1;
 
     const ShadowResolve no_rs = {nullptr, 0, nullptr, nullptr, 0};
+    // chunk cursors instead of the static stride (pt_kernels.h PT_TRACE_DYNAMIC) for the launches over a freshly
+    // filled queue; the pretest launch shares q[0] with the closest-hit launch after it and stays static
+    const int dyn = c->trace_dynamic != 0 ? PT_TRACE_DYNAMIC : 0;
+    const int shade_dyn = c->shade_dynamic != 0 ? 1 : 0;
     auto hit_list = [&](int level) {
         HitList hl{};
         hl.idx = c->hit_idx; hl.count = c->d_counts + 3 * PT_CNT_BLOCK;
         hl.T = c->st.T; hl.L = c->st.L; hl.pstride = c->st.stride;
         memcpy(hl.le, c->sc.le_sum, sizeof(hl.le));
         hl.add_escape = level > 0;
+        hl.dynamic = shade_dyn;
         return hl;
     };
     c->ev_used = 0;
@@ -994,7 +1005,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         }
         {
             StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-            HIPCHK(c, launch_trace(c, false, nb, stream, c->q[0].rays, c->q[0].stride, c->q[0].count, c->q[0].seg, 0,
+            HIPCHK(c, launch_trace(c, false, nb, stream, c->q[0].rays, c->q[0].stride, c->q[0].count, c->q[0].seg, dyn,
                                    c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
         }
         int cur = 0;
@@ -1033,7 +1044,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             {
                 StageTimer tm(c, any_stream, STAGE_TRACE_ANY);
                 HIPCHK(c, launch_trace(c, true, (long)nb * spv, any_stream, sh.rays, sh.stride, sh.count, sh.seg,
-                                       0, nullptr, nullptr, nullptr, nullptr, rs, cnt));
+                                       dyn, nullptr, nullptr, nullptr, nullptr, rs, cnt));
             }
             if (ovl) {
                 HIPCHK(c, hipEventRecord(c->ev_any[sb], c->aux));
@@ -1051,7 +1062,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             }
             if (level + 1 < levels) {
                 StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-                HIPCHK(c, launch_trace(c, false, nb, stream, qout.rays, qout.stride, qout.count, qout.seg, 0, qout.prim,
+                HIPCHK(c, launch_trace(c, false, nb, stream, qout.rays, qout.stride, qout.count, qout.seg, dyn, qout.prim,
                                        qout.t, qout.b1, qout.b2, no_rs, cnt));
                 cur ^= 1;
             }

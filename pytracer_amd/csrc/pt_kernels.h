@@ -48,6 +48,14 @@ __host__ __device__ inline int pt_tile_row_y(const pt_tile &t, int row) {
 // (k_list_hits: 4.9 ms for 67 M entries packed).
 #define PT_CNT_STRIDE 32
 #define PT_CNT_BLOCK (PT_SEG * PT_CNT_STRIDE)
+// Element PT_CNT_CURSOR of a region's line is its chunk cursor: a trace launch with PT_TRACE_DYNAMIC set in `n_val`
+// (segmented input only) lets the waves of a region draw 64-ray chunks from it instead of striding over the region,
+// so waves that drew short rays take more chunks.  It pays when a wave gets few chunks (a shard of a render, a deep
+// bounce): with ~20 chunks per wave the slowest wave of a static launch ends ~15 % after the mean.  The cursor is
+// cleared with the fill counter (the memset of the block / k_raygen), so a queue can be traced dynamically once per
+// fill; results and census do not depend on which wave traced a ray.
+#define PT_CNT_CURSOR 1
+#define PT_TRACE_DYNAMIC 1
 #define PT_SEG_BLOCKS (PT_SEG / (PT_BLOCK / 64))
 
 // ray queue: traced rays and (after K3) their hit records, plus the path slot they belong to
@@ -81,6 +89,7 @@ struct HitList {
     long pstride;
     double le[3];      // Σ light.le
     int add_escape;    // level > 0: a miss adds T * le to L[slot]
+    int dynamic;       // k_shade draws its 64-entry chunks from the region's cursor (PT_CNT_CURSOR) instead of striding
 };
 
 struct ShadowResolve {

@@ -194,7 +194,11 @@ __device__ __forceinline__ void store_result(const TraceOut &o, long i, int res,
     }
 }
 // The rays one thread serves, in both input shapes (below); returns how many.
-template <int BLOCK, class F>
+// DYN: how the kernel compiles the chunk-cursor loop (PT_TRACE_DYNAMIC in n_val; pt_kernels.h): 0 not at all,
+// 1 with the claim for the NEXT chunk in flight while this one is traced (one VGPR held across the walk: its latency is
+// not in the loop), 2 claimed when needed, kept in a scalar register (k_trace_pair: a VGPR more costs its closest-hit
+// form the fifth wave per SIMD, 96 -> 103, and a chunk of its long walks takes 50x the claim's round trip).
+template <int BLOCK, int DYN, class F>
 __device__ __forceinline__ unsigned for_each_ray(const int *__restrict__ seg_counts, long seg, int n_val, F one) {
     unsigned nray = 0;
     if (seg_counts) {
@@ -205,7 +209,18 @@ __device__ __forceinline__ unsigned for_each_ray(const int *__restrict__ seg_cou
         if (sub < nsub) {
             const int n = seg_counts[r * PT_CNT_STRIDE];
             const long first = (long)r * seg;
-            for (int k = sub * 64 + lane; k < n; k += nsub * 64) { one(first + k); nray++; }
+            // ONE loop for both assignments (the walk is inlined once): chunk k of the region, then either the next
+            // claim or the static stride
+            const bool dyn = DYN && (n_val & PT_TRACE_DYNAMIC);
+            int *cursor = const_cast<int *>(seg_counts) + r * PT_CNT_STRIDE + PT_CNT_CURSOR;
+            int claim = (dyn && lane == 0) ? atomicAdd(cursor, 64) : 0;
+            int k = dyn ? __builtin_amdgcn_readfirstlane(claim) : sub * 64;
+            while (k < n) {
+                if (DYN == 1 && dyn) claim = lane == 0 ? atomicAdd(cursor, 64) : 0;
+                if (k + lane < n) { one(first + k + lane); nray++; }
+                if (DYN == 2 && dyn) claim = lane == 0 ? atomicAdd(cursor, 64) : 0;
+                k = dyn ? __builtin_amdgcn_readfirstlane(claim) : k + nsub * 64;
+            }
         }
     } else {
         for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n_val; i += (long)gridDim.x * BLOCK) { one(i); nray++; }
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, c
     __shared__ int s_stack[STACK * PT_BLOCK];
     unsigned nvis = 0, ntri = 0;
     const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
-    const unsigned nray = for_each_ray<PT_BLOCK>(seg_counts, seg, n_val, [&](long i) {
+    const unsigned nray = for_each_ray<PT_BLOCK, 1>(seg_counts, seg, n_val, [&](long i) {
         Ray r = load_ray(rays, stride, i);
         double b1 = 0., b2 = 0.;
         const int res = traverse<ANY>(sc, r, s_stack + threadIdx.x, b1, b2, nvis, ntri);
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_top(DScene sc, const dou
     __syncthreads();
     unsigned nvis = 0, ntri = 0;
     const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
-    const unsigned nray = for_each_ray<PT_TOP_BLOCK>(seg_counts, seg, n_val, [&](long i) {
+    const unsigned nray = for_each_ray<PT_TOP_BLOCK, 2>(seg_counts, seg, n_val, [&](long i) {
         Ray r = load_ray(rays, stride, i);
         double b1 = 0., b2 = 0.;
         const int res = traverse_top<ANY>(sc, top, r, stack, b1, b2, nvis, ntri);
@@ -385,7 +400,7 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_meta(DScene sc, const do
     __syncthreads();
     unsigned nvis = 0, ntri = 0;
     const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
-    const unsigned nray = for_each_ray<PT_TOP_BLOCK>(seg_counts, seg, n_val, [&](long i) {
+    const unsigned nray = for_each_ray<PT_TOP_BLOCK, 1>(seg_counts, seg, n_val, [&](long i) {
         Ray r = load_ray(rays, stride, i);
         double b1 = 0., b2 = 0.;
         int res = ANY ? 0 : -1;
@@ -555,7 +570,10 @@ __device__ __forceinline__ int traverse_pair_loop(const DScene &sc, Ray &r, cons
 
 #define PT_PAIR_BLOCK 256
 #ifndef PT_PAIR_WAVES
-#define PT_PAIR_WAVES 4
+#define PT_PAIR_WAVES 5   // 96 VGPRs (12 bytes of scratch in the closest-hit form, outside the walk); 4 -> 101 VGPRs, same speed static, slower with chunk cursors (soup closest 82.0 vs 80.4 ms)
+#endif
+#ifndef PT_PAIR_DYN
+#define PT_PAIR_DYN 2
 #endif
 template <bool ANY>
 __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair(DScene sc, const double *__restrict__ rays, long stride,
@@ -572,7 +590,7 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair(DSc
     stack.L = lds_levels;
     unsigned nvis = 0, ntri = 0;
     const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
-    const unsigned nray = for_each_ray<PT_PAIR_BLOCK>(seg_counts, seg, n_val, [&](long i) {
+    const unsigned nray = for_each_ray<PT_PAIR_BLOCK, PT_PAIR_DYN>(seg_counts, seg, n_val, [&](long i) {
         Ray r = load_ray(rays, stride, i);
         double b1 = 0., b2 = 0.;
         int res = ANY ? 0 : -1;
@@ -848,6 +866,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
         const int gl = ngroups - 1, jl = gl / PT_SEG;
         if (r == (gl + 17 * jl) % PT_SEG) cnt -= ngroups * gsz - nb;
         q.count[r * PT_CNT_STRIDE] = cnt;
+        q.count[r * PT_CNT_STRIDE + PT_CNT_CURSOR] = 0;      // the chunk cursor of a dynamic trace launch (pt_kernels.h)
     }
     if (i >= nb) return;
     int px, py, si;
@@ -1031,7 +1050,15 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
     const int n = hl.count[region * PT_CNT_STRIDE];     // the entries of this region whose ray hit something (list_hit)
     const int nloop = (n + 63) & ~63;   // whole waves stay convergent for the ballots
     const long first = (long)region * qin.seg;
-    for (int k = sub * 64 + (int)(threadIdx.x & 63); k < nloop; k += nsub * 64) {
+    // chunk kb of the region's hit list: the static stride, or (hl.dynamic) the next claim on the region's cursor — a
+    // claim when needed, held in a scalar register: this kernel has no VGPR to carry a claim across the vertex code
+    const int lane = (int)(threadIdx.x & 63);
+    int *cursor = hl.count + region * PT_CNT_STRIDE + PT_CNT_CURSOR;
+    auto next_chunk = [&](int kb) {
+        return hl.dynamic ? __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(cursor, 64) : 0) : kb + nsub * 64;
+    };
+    for (int kb = hl.dynamic ? next_chunk(0) : sub * 64; kb < nloop; kb = next_chunk(kb)) {
+        const int k = kb + lane;
         const bool live = k < n;
         const long i = first + (live ? hl.idx[first + k] : 0);
         int slot = 0, prim = -1;

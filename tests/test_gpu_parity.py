@@ -137,7 +137,8 @@ def test_axis_parallel_rays_on_box_planes(torch_cuda, ctx, golden_dir):
     assert (gs.node_visits, gs.tri_tests) == (os_.node_visits, os_.tri_tests)
 
 
-@pytest.mark.parametrize('knob', [('PT_TRACE_TOP', '1'), ('PT_TRACE_META', '2'), ('PT_TRACE_META', '0'), ('PT_TRACE_PAIR', '3')])
+@pytest.mark.parametrize('knob', [('PT_TRACE_TOP', '1'), ('PT_TRACE_META', '2'), ('PT_TRACE_META', '0'), ('PT_TRACE_PAIR', '3'),
+                                  ('PT_TRACE_DYNAMIC', '1'), ('PT_TRACE_DYNAMIC', '0')])
 def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head, knob):
     """k_trace_top (first breadth-first nodes staged in LDS; default only for trees beyond the L2), k_trace_meta
     (child/primitive words of all nodes in LDS; default for closest-hit launches on small trees), k_trace_pair (the
@@ -174,6 +175,53 @@ def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head
         assert rel_err(L, d['L']) < REF_RTOL
     finally:
         c.close()
+
+
+@pytest.mark.parametrize('kind', [A.PT_INTEG_PATH, A.PT_INTEG_DIRECT])
+def test_dynamic_chunk_assignment_changes_nothing(torch_cuda, golden_dir, head, kind):
+    """PT_TRACE_DYNAMIC: the waves of a queue region draw their 64-ray chunks from a cursor instead of striding over
+    the region.  Which wave traces a ray is not observable: per-sample radiance equal to the last bits (the shadow
+    contributions are atomic adds whose order is free in both forms), census equal, on a production-stream render large
+    enough that every region holds many chunks, whole and as an interleaved shard."""
+    from pytracer_amd._lib import Context
+    from pytracer_amd.renderer import shard_tile
+    R = 512                                  # 1 M samples: 16 k chunks for 4 096 waves
+    sub, spp = (0, R, 0, R), (2, 2)
+    out = {}
+    for dyn in ('0', '1'):
+        os.environ['PT_TRACE_DYNAMIC'] = dyn
+        os.environ['PT_OVERLAP'] = '0'          # one stream: the order of the adds into L is then the launch order
+        try:
+            c = Context(0)
+        finally:
+            del os.environ['PT_TRACE_DYNAMIC'], os.environ['PT_OVERLAP']
+        try:
+            c.upload(head[1])
+            res = []
+            smp = pa.sampler_desc(*sub, spp[0], spp[1], True, 0)
+            for tile in (None, shard_tile(smp, 1, 3, 'interleaved')):
+                st = A.pt_stats()
+                cam, film = host_camera_film(R)
+                n = R * (R if tile is None else tile.rows()) * 4
+                t = tile if tile is not None else pa.tile_desc(*sub, 0, 4)
+                acc = torch_cuda.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch_cuda.float64, device='cuda')
+                L = torch_cuda.zeros((n, 3), dtype=torch_cuda.float64, device='cuda')
+                c.render(cam, film, smp, pa.integrator_desc(kind, 5, False), t, acc, sample_L=L, stats=st)
+                torch_cuda.cuda.synchronize()
+                res.append((acc.cpu().numpy(), L.cpu().numpy(), st.as_dict()))
+            out[dyn] = res
+        finally:
+            c.close()
+    assert out['0'][0][2]['rays_closest'] >= R * R * 4
+    for (a0, l0, s0), (a1, l1, s1) in zip(out['0'], out['1']):
+        assert s0 == s1
+        np.testing.assert_allclose(l1, l0, rtol=1e-13, atol=0)
+        np.testing.assert_allclose(a1, a0, rtol=1e-11, atol=1e-14)
+
+
+def host_camera_film(res):
+    from pytracer_amd import host
+    return host.head_mesh_camera_film(res, res)
 
 
 def test_intersect_edge_cases(torch_cuda, ctx, golden_dir, head):
