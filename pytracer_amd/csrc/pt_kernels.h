@@ -42,7 +42,9 @@ __host__ __device__ inline int pt_tile_row_y(const pt_tile &t, int row) {
 // With ONE counter per queue the ~1 M wave-level appends of a 64 M-sample level serialised on
 // one L2 word (~88 atomics/us, MI355X_MICROARCH.md) and cost more than the shading itself.
 // Grids of kernels that walk a segmented queue are multiples of PT_SEG_BLOCKS workgroups.
+#ifndef PT_SEG
 #define PT_SEG 64
+#endif
 // Region r's fill counter is element r * PT_CNT_STRIDE of a counter block: one 128-byte line each.
 // Packed, the 64 counters shared two lines and every append in the chip serialised on them in L2
 // (k_list_hits: 4.9 ms for 67 M entries packed).

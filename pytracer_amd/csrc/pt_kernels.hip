@@ -234,7 +234,7 @@ __device__ __forceinline__ unsigned for_each_ray(const int *__restrict__ seg_cou
 //    entries, region r filled to seg_counts[r]; wave w serves region w % PT_SEG together with
 //    the other waves of the same residue.
 // Scheduling alternatives measured and rejected (while-while, lane refill, software prefetch of the
-// next node, scalar loads for wave-uniform nodes, dynamic and permuted chunk assignment) are in the
+// next node, scalar loads for wave-uniform nodes, permuted chunk assignment) are in the
 // history of this file and in DESIGN.md "trace: what was tried".
 template <int STACK, bool ANY>
 __global__ __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) void k_trace(DScene sc, const double *__restrict__ rays, long stride,

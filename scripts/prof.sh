@@ -7,6 +7,9 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+# one stream: with the render's two streams kernels overlap and a launch's start-to-end time includes sharing the machine
+# (closest-hit launches read 7.0 ms instead of 6.4); the roofline prices the kernel alone (bench.py)
+export PT_OVERLAP=0
 run() {  # name, rocprof args...
     local name=$1; shift
     timeout -s KILL 400 rocprofv3 "$@" -d $out/$name -o p -- python3 bench.py --no-cpu-baseline "${BARGS[@]}" > $out/$name.json 2> $out/$name.err || { echo "pass $name failed"; tail -5 $out/$name.err; exit 1; }
