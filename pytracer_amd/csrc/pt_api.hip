@@ -842,6 +842,7 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv, int gshift) {
     size_t off_T = need(3 * cap * sizeof(double)), off_L = need(3 * cap * sizeof(double));
     size_t off_img = need(2 * cap * sizeof(double));
     size_t off_hit = need(cap * sizeof(int));
+    size_t off_esc = need(cap * sizeof(int));
     HIPCHK(c, hipMalloc(&c->ws, bytes));
     char *b = (char *)c->ws;
     for (int k = 0; k < 2; k++) {
@@ -857,6 +858,7 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv, int gshift) {
         sh.stride = sh_cap; sh.seg = seg * spv; sh.count = c->d_counts + (k ? 4 : 2) * PT_CNT_BLOCK;
     }
     c->st.T = (double *)(b + off_T); c->st.L = (double *)(b + off_L); c->st.img = (double *)(b + off_img);
+    c->st.esc = (int *)(b + off_esc);
     c->st.stride = cap;
     c->hit_idx = (int *)(b + off_hit);
     c->cap = cap; c->sh_cap = sh_cap; c->ws_bytes = bytes;
@@ -939,7 +941,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t per_path = 8 * 8 * 2 + 4 * 2 * 2 + 8 * 3 * 2 + 2 * (8 * 11 + 4) * (size_t)std::max(1, ig->kind == PT_INTEG_DIRECT ? c->shadow_per_vertex_direct : (ig->kind == PT_INTEG_WHITTED ? c->sc.n_lights : 1)) + 8 * 8;
+            const size_t per_path = 8 * 8 * 2 + 4 * 2 * 2 + 8 * 3 * 2 + 2 * (8 * 11 + 4) * (size_t)std::max(1, ig->kind == PT_INTEG_DIRECT ? c->shadow_per_vertex_direct : (ig->kind == PT_INTEG_WHITTED ? c->sc.n_lights : 1)) + 8 * 8 + 4;
             const size_t budget = (free_b + c->ws_bytes) / 2;     // leave half of what is free to the caller
             const long fit = (long)(budget / per_path);
             if (fit < batch) batch = std::max(fit, 1l << 16);
@@ -955,6 +957,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     while (gshift < 6 && ((batch / 64) >> (gshift + 1)) >= 4 * PT_SEG) gshift++;
     int rc = ensure_workspace(c, batch, spv, gshift);
     if (rc != PT_OK) return rc;
+    memcpy(c->st.le, c->sc.le_sum, sizeof(c->st.le));
 
     // a previous pt_render that failed half-way may have left any-hit traces running on the second stream: nothing of
     // this call may touch the queues before they are done
@@ -983,8 +986,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     auto hit_list = [&](int level) {
         HitList hl{};
         hl.idx = c->hit_idx; hl.count = c->d_counts + 3 * PT_CNT_BLOCK;
-        hl.T = c->st.T; hl.L = c->st.L; hl.pstride = c->st.stride;
-        memcpy(hl.le, c->sc.le_sum, sizeof(hl.le));
+        hl.esc = c->st.esc;
         hl.add_escape = level > 0;
         hl.dynamic = shade_dyn;
         return hl;

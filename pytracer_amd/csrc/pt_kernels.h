@@ -86,11 +86,8 @@ struct ShadowQueue {
 struct HitList {
     int *idx;          // [stride] region-local entry numbers, dense from region * seg; nullptr = off
     int *count;        // [PT_SEG]
-    const double *T;   // path state, for the rays that escaped
-    double *L;
-    long pstride;
-    double le[3];      // Σ light.le
-    int add_escape;    // level > 0: a miss adds T * le to L[slot]
+    int *esc;          // PathState::esc
+    int add_escape;    // level > 0: a miss marks its path escaped (esc[slot] = 1); k_splat adds T * Σ light.le for it
     int dynamic;       // k_shade draws its 64-entry chunks from the region's cursor (PT_CNT_CURSOR) instead of striding
 };
 
@@ -107,6 +104,11 @@ struct PathState {
     double *T;     // [3][stride] path throughput
     double *L;     // [3][stride] accumulated radiance
     double *img;   // [2][stride] imageX, imageY
+    int *esc;      // [stride] 1: the path's continuation ray left the scene (k_list_hits).  A path escapes at most once
+                   // and its throughput is not touched afterwards, so the radiance it picks up there, T * Σ light.le
+                   // (renderer.py:66-68 / path.py:130-135), is added when the sample is splatted: a plain 4-byte store per
+                   // escaped ray instead of three scattered binary64 atomics + three loads (k_list_hits 1.30 -> see DESIGN)
+    double le[3];  // Σ light.le
     long stride;
 };
 

@@ -917,6 +917,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
     const long P = st.stride;
     st.T[i] = 1.; st.T[P + i] = 1.; st.T[2 * P + i] = 1.;
     st.L[i] = 0.; st.L[P + i] = 0.; st.L[2 * P + i] = 0.;
+    st.esc[i] = 0;
     st.img[i] = ix; st.img[P + i] = iy;
     if (counters && threadIdx.x == 0) {
         int cnt = nb - blockIdx.x * PT_BLOCK;
@@ -1221,27 +1222,45 @@ hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc,
 // ~70 % of the head-mesh rays escape; shading them in place left most lanes of every wave idle
 // (shade 25 -> 18 ms per step).  A pass of its own, ~0.1 ms per million entries: inside k_trace the
 // extra live state spilled at the 80-VGPR budget and cost more than it saved.
+// A wave takes PT_LIST_UNROLL consecutive 64-entry chunks per step: their `prim` loads are in flight together and ONE
+// atomic (with return: the dependent step of the loop) reserves the list positions of all of them — at one chunk per
+// step the waves sat parked on that round trip 91 % of their cycles (profiles/r02_head_sq.csv: 0.58 ms per launch).
+#define PT_LIST_UNROLL 4
 __global__ __launch_bounds__(PT_BLOCK) void k_list_hits(Queue q, HitList hl) {
     const int wave = (int)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6);
     const int nsub = (int)((gridDim.x * (PT_BLOCK / 64)) / PT_SEG);
     const int region = wave % PT_SEG, sub = wave / PT_SEG;
     if (sub >= nsub) return;
+    const int lane = (int)(threadIdx.x & 63);
     const int n = q.count[region * PT_CNT_STRIDE];
-    const int nloop = (n + 63) & ~63;
     const long first = (long)region * q.seg;
-    for (int k = sub * 64 + (int)(threadIdx.x & 63); k < nloop; k += nsub * 64) {
-        const bool live = k < n;
-        const int prim = live ? q.prim[first + k] : -1;
-        if (live && prim < 0 && hl.add_escape) {
-            const int slot = q.slot[first + k];
-            const long P = hl.pstride;
-            // atomic: the previous level's shadow trace may be adding to the same L[slot] on the other stream
-            unsafeAtomicAdd(hl.L + slot, hl.T[slot] * hl.le[0]);
-            unsafeAtomicAdd(hl.L + P + slot, hl.T[P + slot] * hl.le[1]);
-            unsafeAtomicAdd(hl.L + 2 * P + slot, hl.T[2 * P + slot] * hl.le[2]);
+    for (int kb = sub * (64 * PT_LIST_UNROLL); kb < n; kb += nsub * (64 * PT_LIST_UNROLL)) {
+        int prim[PT_LIST_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PT_LIST_UNROLL; u++) {
+            const int k = kb + u * 64 + lane;
+            prim[u] = k < n ? q.prim[first + k] : 0;          // 0: past the end counts neither as a hit nor as an escape
         }
-        const int pos = wave_append(prim >= 0, hl.count + region * PT_CNT_STRIDE);
-        if (pos >= 0) hl.idx[first + pos] = k;
+        unsigned long long mask[PT_LIST_UNROLL];
+        int total = 0;
+#pragma unroll
+        for (int u = 0; u < PT_LIST_UNROLL; u++) {
+            const int k = kb + u * 64 + lane;
+            const bool live = k < n;
+            if (live && prim[u] < 0 && hl.add_escape) hl.esc[q.slot[first + k]] = 1;
+            mask[u] = __ballot(live && prim[u] >= 0);
+            total += __popcll(mask[u]);
+        }
+        if (total == 0) continue;                             // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(hl.count + region * PT_CNT_STRIDE, total);
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int u = 0; u < PT_LIST_UNROLL; u++) {
+            const int k = kb + u * 64 + lane;
+            if (k < n && prim[u] >= 0) hl.idx[first + base + (int)lane_prefix(mask[u])] = k;
+            base += __popcll(mask[u]);
+        }
     }
 }
 
@@ -1390,7 +1409,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_splat(const RenderConst *__restric
                 const long out_i = pix_i + sidx;
                 if (sidx >= ns || out_i < base || out_i >= base + nb) continue;
                 const int slot = (int)(out_i - base);
-                d3 L = guarded_radiance(mk3(st.L[slot], st.L[P + slot], st.L[2 * P + slot]), counters);
+                d3 Lraw = mk3(st.L[slot], st.L[P + slot], st.L[2 * P + slot]);
+                if (st.esc[slot])        // the path's last ray escaped: L += T * Σ light.le, after all its other terms
+                    Lraw = Lraw + mk3(st.T[slot] * st.le[0], st.T[P + slot] * st.le[1], st.T[2 * P + slot] * st.le[2]);
+                d3 L = guarded_radiance(Lraw, counters);
                 if (sample_L) {
                     sample_L[3 * out_i] = L.x; sample_L[3 * out_i + 1] = L.y; sample_L[3 * out_i + 2] = L.z;
                 }
