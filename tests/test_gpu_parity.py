@@ -137,8 +137,8 @@ def test_axis_parallel_rays_on_box_planes(torch_cuda, ctx, golden_dir):
     assert (gs.node_visits, gs.tri_tests) == (os_.node_visits, os_.tri_tests)
 
 
-@pytest.mark.parametrize('knob', [('PT_TRACE_TOP', '1'), ('PT_TRACE_META', '2'), ('PT_TRACE_META', '0'), ('PT_TRACE_PAIR', '3'),
-                                  ('PT_TRACE_DYNAMIC', '1'), ('PT_TRACE_DYNAMIC', '0')])
+@pytest.mark.parametrize('knob', ['PT_TRACE_TOP=1', 'PT_TRACE_META=2', 'PT_TRACE_META=0', 'PT_TRACE_PAIR=3',
+                                  'PT_TRACE_DYNAMIC=1', 'PT_TRACE_DYNAMIC=0', 'PT_TRACE_META=2,PT_TRACE_DYNAMIC=0'])
 def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head, knob):
     """k_trace_top (first breadth-first nodes staged in LDS; default only for trees beyond the L2), k_trace_meta
     (child/primitive words of all nodes in LDS; default for closest-hit launches on small trees), k_trace_pair (the
@@ -146,11 +146,13 @@ def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head
     and the plain k_trace walk the same nodes in the same order: outputs and visit counts equal the oracle's."""
     import oracle_lib as O
     from pytracer_amd._lib import Context
-    os.environ[knob[0]] = knob[1]
+    kv = dict(x.split('=') for x in knob.split(','))
+    os.environ.update(kv)
     try:
         c = Context(0)
     finally:
-        del os.environ[knob[0]]
+        for k in kv:
+            del os.environ[k]
     try:
         cases = [(head[1], head[2], rays_from_log(load(golden_dir, 'head_path_32x32x4.npz')['log_rays']))]
         for name in ('bvh_soup2000.npz', 'bvh_soup500dup.npz'):
