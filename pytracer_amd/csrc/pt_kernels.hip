@@ -915,7 +915,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
     q.rays[6 * S + e] = 0.; q.rays[7 * S + e] = __builtin_inf();
     q.slot[e] = i;
     const long P = st.stride;
-    st.T[i] = 1.; st.T[P + i] = 1.; st.T[2 * P + i] = 1.;
+    // st.T is not initialised: level 0 shades with T = 1 and writes it with the first continuation ray
     st.L[i] = 0.; st.L[P + i] = 0.; st.L[2 * P + i] = 0.;
     st.esc[i] = 0;
     st.img[i] = ix; st.img[P + i] = iy;
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
         if (live) { slot = qin.slot[i]; prim = qin.prim[i]; }
         const long P = st.stride, S = qin.stride;
         d3 T = mk3(0, 0, 0);
-        if (live) T = mk3(st.T[slot], st.T[P + slot], st.T[2 * P + slot]);
+        if (live) T = level == 0 ? mk3(1., 1., 1.) : mk3(st.T[slot], st.T[P + slot], st.T[2 * P + slot]);
         const bool hit = live && prim >= 0;
         Ray ray;
         VertexT<R> vx;
