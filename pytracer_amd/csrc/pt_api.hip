@@ -25,6 +25,7 @@ struct pt_ctx {
     int n_pairs;
     int use_pair;            // PT_TRACE_PAIR: 0 never, 1 always, unset (-1) = by tree size (launch_trace)
     int shade_dynamic;       // PT_SHADE_DYNAMIC: the same for k_shade's walk over the hit list
+    int pair_refill;         // PT_PAIR_REFILL: k_trace_pair launches of a render refill their lanes (needs the cursors); unset (-1) = by tree size
     int trace_dynamic;       // PT_TRACE_DYNAMIC: 0 = static chunk assignment in the trace launches of a render, else (default) chunk cursors
     size_t brdf_bytes;
     int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
@@ -171,6 +172,8 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     c->overlap = 1;
     if (const char *e = getenv("PT_OVERLAP")) c->overlap = atoi(e);
     c->trace_dynamic = -1;
+    c->pair_refill = -1;
+    if (const char *e = getenv("PT_PAIR_REFILL")) c->pair_refill = atoi(e);
     c->shade_dynamic = -1;
     if (const char *e = getenv("PT_SHADE_DYNAMIC")) c->shade_dynamic = atoi(e);
     if (const char *e = getenv("PT_TRACE_DYNAMIC")) c->trace_dynamic = atoi(e);
@@ -711,9 +714,11 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
         long grid = std::max<long>(1, std::min<long>(blocks, (long)c->n_cu * per_cu));
         if (seg_counts) grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
         grid = std::min<long>(grid, c->pair_max_blocks);                                        // what the spill area holds
+        // lane refill (k_trace_pair_refill) pays where walks are long and uneven: by tree size unless PT_PAIR_REFILL says
+        const bool refill = c->pair_refill < 0 ? c->sc.n_nodes >= (1 << 20) : c->pair_refill != 0;
         char *spill = (char *)c->d_spill + (any ? pt_trace_pair_spill_bytes(c->pair_levels, c->pair_max_blocks * 256) : 0);
         return pt_launch_trace_pair(any, c->pair_lds_levels, spill, (int)grid, stream, c->sc, rays, stride, seg_counts,
-                                    seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+                                    seg, (seg_counts && refill) ? (n_val | PT_TRACE_REFILL) : n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
     }
     if (c->meta_stack > 0 && c->use_top <= 0 && (c->use_meta > 1 || (c->use_meta == 1 && !any))) {
         const long blocks = (n_bound + 1023) / 1024;

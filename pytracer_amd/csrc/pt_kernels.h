@@ -58,6 +58,7 @@ __host__ __device__ inline int pt_tile_row_y(const pt_tile &t, int row) {
 // fill; results and census do not depend on which wave traced a ray.
 #define PT_CNT_CURSOR 1
 #define PT_TRACE_DYNAMIC 1
+#define PT_TRACE_REFILL 2    // with PT_TRACE_DYNAMIC, k_trace_pair launches: lanes that finish take new rays (k_trace_pair_refill)
 #define PT_SEG_BLOCKS (PT_SEG / (PT_BLOCK / 64))
 
 // ray queue: traced rays and (after K3) their hit records, plus the path slot they belong to

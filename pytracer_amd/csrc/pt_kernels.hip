@@ -465,6 +465,113 @@ __device__ __forceinline__ PairEnt pair_pop(const PairStack &st, int level) {
     return st.spill[(long)(level - st.L) * st.spill_stride];
 }
 
+// The root: a visit like any other.  false = the ray misses the whole tree.
+__device__ __forceinline__ bool pair_root(const DScene &sc, const Ray &r, const SlabRay &sv, int &ref, unsigned &nvis) {
+    const double2 *q = reinterpret_cast<const double2 *>(sc.nodes);
+    const double2 n0 = q[0], n1 = q[1], n2 = q[2];
+    const int2 meta = *reinterpret_cast<const int2 *>(&q[3]);
+    nvis++;
+    if (!slab_hit<true>(n0, n1, n2, r, sv)) return false;
+    ref = (meta.y & 0xFFFF) ? ~meta.x : 0;
+    return true;
+}
+
+// One step of the walk: the visit `ref` stands for (a hit leaf's primitives, or a pair record = two child visits) and
+// the pops that follow it.  true = the walk of this ray is over (`result` holds its outcome).
+template <bool ANY, int BLOCK>
+__device__ __forceinline__ bool pair_step(const DScene &sc, Ray &r, const SlabRay &sv, const PairStack &stack, int &ref,
+                                          int &todo, unsigned &pend, int &result, double &b1o, double &b2o,
+                                          unsigned &nvis, unsigned &ntri) {
+    int next;
+    if (ref < 0) {
+        // a leaf whose box was hit: its primitives in order (bvh.py:339-345 / :384-390)
+        const int first = ~ref;
+        int n = 1;
+        for (int i = 0; i < n; i++) {
+            const double2 *q = reinterpret_cast<const double2 *>(sc.tris + first + i);
+            const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+            if (i == 0) n = __double2loint(a4.y);          // GTri::leaf_nprim
+            double t, b1, b2;
+            ntri++;
+            if (tri_math(a0, a1, a2, a3, a4, r, t, b1, b2)) {
+                if (ANY) { result = 1; return true; }
+                result = first + i;
+                b1o = b1; b2o = b2;
+                r.maxt = t;
+            }
+        }
+        next = PT_PAIR_POP;
+    } else {
+        const double2 *q = reinterpret_cast<const double2 *>(sc.pairs + ref);
+        const double2 c0 = q[0], c1 = q[1], c2 = q[2], d0 = q[3], d1 = q[4], d2 = q[5];
+        const int4 m = *reinterpret_cast<const int4 *>(&q[6]);         // ref0, ref1, axis, self
+        // both slab tests in the fast form (slab_hit<true>)
+        const double ax0 = (c0.x - r.o.x) * sv.invx, ax1 = (c1.y - r.o.x) * sv.invx;
+        const double ay0 = (c0.y - r.o.y) * sv.invy, ay1 = (c2.x - r.o.y) * sv.invy;
+        const double az0 = (c1.x - r.o.z) * sv.invz, az1 = (c2.y - r.o.z) * sv.invz;
+        const double bx0 = (d0.x - r.o.x) * sv.invx, bx1 = (d1.y - r.o.x) * sv.invx;
+        const double by0 = (d0.y - r.o.y) * sv.invy, by1 = (d2.x - r.o.y) * sv.invy;
+        const double bz0 = (d1.x - r.o.z) * sv.invz, bz1 = (d2.y - r.o.z) * sv.invz;
+        const double tn0 = fmax(fmax(fmin(ax0, ax1), fmin(ay0, ay1)), fmin(az0, az1));
+        const double tf0 = fmin(fmin(fmax(ax0, ax1), fmax(ay0, ay1)), fmax(az0, az1));
+        const double tn1 = fmax(fmax(fmin(bx0, bx1), fmin(by0, by1)), fmin(bz0, bz1));
+        const double tf1 = fmin(fmin(fmax(bx0, bx1), fmax(by0, by1)), fmax(bz0, bz1));
+        const bool ok0 = (tn0 <= tf0) && (tn0 < r.maxt) && (tf0 > r.mint);
+        const bool ok1 = (tn1 <= tf1) && (tn1 < r.maxt) && (tf1 > r.mint);
+        const bool neg = (sv.negmask >> m.z) & 1;                       // near child = second child when negative
+        const bool okN = neg ? ok1 : ok0, okF = neg ? ok0 : ok1;
+        const int refN = neg ? m.y : m.x, refF = neg ? m.x : m.y;
+        nvis++;                                                         // the near child's visit
+        if (okN) {
+            if (okF) {
+                PairEnt e;
+                e.ref = refF;
+                e.aux = ANY ? (int)pend : __double2hiint(neg ? tn0 : tn1);
+                pair_push<BLOCK>(stack, todo, e);
+                todo++;
+                pend = 0;
+            } else if (ANY) pend++;
+            else nvis++;                                                // closest: it will be popped and missed
+            next = refN;
+        } else {
+            nvis++;                                                     // the far child is popped right away
+            next = okF ? refF : PT_PAIR_POP;
+        }
+    }
+    if (next == PT_PAIR_POP) {
+        if (ANY) {
+            nvis += pend;
+            if (todo == 0) return true;
+            todo--;
+            const PairEnt e = pair_pop<BLOCK>(stack, todo);
+            nvis++;
+            pend = (unsigned)e.aux;
+            next = e.ref;
+        } else {
+            for (;;) {
+                if (todo == 0) return true;
+                todo--;
+                const PairEnt e = pair_pop<BLOCK>(stack, todo);
+                nvis++;
+                // tnear lies between the two doubles that share its high word
+                const double lo = __hiloint2double(e.aux, 0), hi = __hiloint2double(e.aux, (int)0xFFFFFFFF);
+                const bool sure_hit = (r.maxt > lo) && (r.maxt > hi);
+                const bool sure_miss = (r.maxt <= lo) && (r.maxt <= hi);
+                bool hit = sure_hit;
+                if (!sure_hit && !sure_miss) hit = exact_tnear_lt_maxt(sc, e.ref, r, sv.invx, sv.invy, sv.invz);
+                if (hit) { next = e.ref; break; }
+            }
+        }
+    }
+    ref = next;
+    return false;
+}
+
+// The whole walk of one ray.  NOT written as `while (!pair_step(...))`, although it is that, statement for statement:
+// from that form the compiler rotates the loop so that lanes going from one pair to the next spin in an inner loop
+// while the lanes at leaves and pops wait for them (soup closest-hit traces 81 -> 111 ms; the same pathology as the
+// if/else form of traverse_loop).  k_trace_pair_refill is safe from it: the ballot at the top of
+// its loop is a convergent operation no lane may skip.
 template <bool ANY, int BLOCK>
 __device__ __forceinline__ int traverse_pair_loop(const DScene &sc, Ray &r, const SlabRay &sv, const PairStack &stack,
                                                   double &b1o, double &b2o, unsigned &nvis, unsigned &ntri) {
@@ -606,6 +713,90 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair(DSc
     if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
 }
 
+// k_trace_pair_refill: the same walk with the wave's lanes kept busy.  A chunk of 64 rays ends with its longest ray: on
+// the 10^6-triangle soup the lanes of k_trace_pair are busy 31 % of a wave's steps (sum of visits / 64 x longest
+// lane, measured), and that walk is bound by the latency of its fetches, not by their number — an idle lane is a
+// fetch not in flight.  Here a lane that finishes its ray stores the result and waits; once PT_REFILL_MIN lanes wait
+// (or the wave has nothing left), the wave claims that many rays from the region's cursor (one atomic) and the waiting
+// lanes start on them.  Segmented input with PT_TRACE_DYNAMIC only (the cursor); per-ray results and the census
+// cannot depend on which lane walks a ray.  A refill costs the wave a claim, the ray loads and the set-up code at a
+// fraction of its lanes (~4 us): waiting for 4 / 8 / 16 / 24 / 32 / 48 lanes gives 74.4 / 71.0 / 67.8 / 66.1 / 65.5 /
+// 66.9 ms for the soup's closest-hit traces (81.0 without refill).  On head_loop (352 k nodes, 46 visits per ray, lanes
+// 59 % busy) it loses at every setting (closest 1.5 vs 1.3 ms): pt_api.hip turns it on for trees of 2^20 nodes or more.
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 32
+#endif
+template <bool ANY>
+__global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair_refill(
+    DScene sc, const double *__restrict__ rays, long stride, const int *__restrict__ seg_counts, long seg,
+    int *__restrict__ out_prim, double *__restrict__ out_t, double *__restrict__ out_b1, double *__restrict__ out_b2,
+    ShadowResolve rs, unsigned long long *counters, PairEnt *__restrict__ spill, int lds_levels, int refill_min) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    PairStack stack;
+    stack.lds = reinterpret_cast<PairEnt *>(s_mem) + threadIdx.x;
+    stack.spill = spill + ((long)blockIdx.x * PT_PAIR_BLOCK + threadIdx.x);
+    stack.spill_stride = (long)gridDim.x * PT_PAIR_BLOCK;
+    stack.L = lds_levels;
+    unsigned nvis = 0, ntri = 0, nray = 0;
+    const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * PT_PAIR_BLOCK + threadIdx.x) >> 6);
+    const int nsub = (int)((gridDim.x * (PT_PAIR_BLOCK / 64)) / PT_SEG);
+    const int region = wave % PT_SEG;
+    if (wave / PT_SEG < nsub && sc.n_nodes > 0) {
+        const int n = seg_counts[region * PT_CNT_STRIDE];
+        const long first = (long)region * seg;
+        int *cursor = const_cast<int *>(seg_counts) + region * PT_CNT_STRIDE + PT_CNT_CURSOR;
+        bool more = n > 0;                 // wave-uniform: the region may still hold unclaimed rays
+        bool have = false;
+        int k = 0, ref = 0, todo = 0, result = 0;
+        unsigned pend = 0;
+        Ray r;
+        SlabRay sv;
+        double b1 = 0., b2 = 0.;
+        r.o = r.d = mk3(0, 0, 0); r.mint = 0.; r.maxt = 0.;
+        sv.invx = sv.invy = sv.invz = 0.; sv.negx = sv.negy = sv.negz = false; sv.negmask = 0; sv.fast = true;
+        for (;;) {
+            const unsigned long long waiting = __ballot(!have);
+            const int nwait = __popcll(waiting);
+            if (more && (nwait >= refill_min || nwait == 64)) {
+                int base = lane == 0 ? atomicAdd(cursor, nwait) : 0;
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base + nwait >= n) more = false;
+                if (!have) {
+                    k = base + (int)lane_prefix(waiting);
+                    if (k < n) {
+                        r = load_ray(rays, stride, first + k);
+                        b1 = 0.; b2 = 0.;
+                        result = ANY ? 0 : -1;
+                        todo = 0; pend = 0;
+                        sv = slab_ray(sc, r);
+                        nray++;
+                        bool walking;
+                        if (sv.fast) walking = pair_root(sc, r, sv, ref, nvis);
+                        else {     // the literal walk, to its end: rare (zero / NaN direction components)
+                            result = traverse_loop<ANY, false>(sc, r, sv, reinterpret_cast<int *>(stack.spill), b1, b2, nvis,
+                                                               ntri, 2 * stack.spill_stride);
+                            walking = false;
+                        }
+                        if (walking) have = true;
+                        else store_result<ANY>(out, first + k, result, r, b1, b2);
+                    }
+                }
+            }
+            if (__ballot(have) == 0ull) {
+                if (!more) break;
+                continue;                  // every claimed ray ended at once (missed the root): claim again
+            }
+            if (have && pair_step<ANY, PT_PAIR_BLOCK>(sc, r, sv, stack, ref, todo, pend, result, b1, b2, nvis, ntri)) {
+                store_result<ANY>(out, first + k, result, r, b1, b2);
+                have = false;
+            }
+        }
+    }
+    if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
+}
+
 size_t pt_trace_pair_lds(int lds_levels) { return (size_t)lds_levels * PT_PAIR_BLOCK * sizeof(PairEnt); }
 size_t pt_trace_pair_spill_bytes(int levels, long grid_threads) { return (size_t)levels * (size_t)grid_threads * sizeof(PairEnt); }
 
@@ -627,14 +818,27 @@ hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid,
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
     if (!attr_set[dev][any ? 1 : 0]) {
-        hipError_t e = any ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_pair<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_pair<false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
+        const void *fns[2] = {any ? reinterpret_cast<const void *>(&k_trace_pair<true>) : reinterpret_cast<const void *>(&k_trace_pair<false>),
+                              any ? reinterpret_cast<const void *>(&k_trace_pair_refill<true>)
+                                  : reinterpret_cast<const void *>(&k_trace_pair_refill<false>)};
+        for (const void *fn : fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         attr_set[dev][any ? 1 : 0] = true;
     }
-    if (any)
+    // lane refill needs the region cursors: segmented input of a launch with PT_TRACE_DYNAMIC
+    const bool refill = seg_counts && (n_val & PT_TRACE_DYNAMIC) && (n_val & PT_TRACE_REFILL);
+    static int refill_min = 0;
+    if (!refill_min) { const char *e = getenv("PT_REFILL_MIN"); refill_min = e && atoi(e) > 0 ? atoi(e) : PT_REFILL_MIN; }
+    if (refill) {
+        if (any)
+            hipLaunchKernelGGL((k_trace_pair_refill<true>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride,
+                               seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, refill_min);
+        else
+            hipLaunchKernelGGL((k_trace_pair_refill<false>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride,
+                               seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, refill_min);
+    } else if (any)
         hipLaunchKernelGGL((k_trace_pair<true>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride, seg_counts,
                            seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels);
     else

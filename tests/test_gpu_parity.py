@@ -181,22 +181,26 @@ def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head
 
 @pytest.mark.parametrize('kind', [A.PT_INTEG_PATH, A.PT_INTEG_DIRECT])
 def test_dynamic_chunk_assignment_changes_nothing(torch_cuda, golden_dir, head, kind):
-    """PT_TRACE_DYNAMIC: the waves of a queue region draw their 64-ray chunks from a cursor instead of striding over
-    the region.  Which wave traces a ray is not observable: per-sample radiance equal to the last bits (the shadow
+    """PT_TRACE_DYNAMIC / PT_SHADE_DYNAMIC: the waves of a queue region draw their 64-ray chunks from a cursor instead
+    of striding over the region; PT_PAIR_REFILL: the lanes of k_trace_pair take new rays from that cursor as they finish
+    (k_trace_pair_refill).  Which wave or lane traces a ray is not observable: per-sample radiance equal to the last bits (the shadow
     contributions are atomic adds whose order is free in both forms), census equal, on a production-stream render large
     enough that every region holds many chunks, whole and as an interleaved shard."""
     from pytracer_amd._lib import Context
     from pytracer_amd.renderer import shard_tile
     R = 512                                  # 1 M samples: 16 k chunks for 4 096 waves
     sub, spp = (0, R, 0, R), (2, 2)
-    out = {}
-    for dyn in ('0', '1'):
-        os.environ['PT_TRACE_DYNAMIC'] = dyn
-        os.environ['PT_OVERLAP'] = '0'          # one stream: the order of the adds into L is then the launch order
+    settings = [{'PT_TRACE_DYNAMIC': '0', 'PT_SHADE_DYNAMIC': '0'}, {},
+                {'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '0'}, {'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1'}]
+    out = []
+    for env in settings:
+        env = dict(env, PT_OVERLAP='0')         # one stream: the order of the adds into L is then the launch order
+        os.environ.update(env)
         try:
             c = Context(0)
         finally:
-            del os.environ['PT_TRACE_DYNAMIC'], os.environ['PT_OVERLAP']
+            for k in env:
+                del os.environ[k]
         try:
             c.upload(head[1])
             res = []
@@ -211,14 +215,15 @@ def test_dynamic_chunk_assignment_changes_nothing(torch_cuda, golden_dir, head, 
                 c.render(cam, film, smp, pa.integrator_desc(kind, 5, False), t, acc, sample_L=L, stats=st)
                 torch_cuda.cuda.synchronize()
                 res.append((acc.cpu().numpy(), L.cpu().numpy(), st.as_dict()))
-            out[dyn] = res
+            out.append(res)
         finally:
             c.close()
-    assert out['0'][0][2]['rays_closest'] >= R * R * 4
-    for (a0, l0, s0), (a1, l1, s1) in zip(out['0'], out['1']):
-        assert s0 == s1
-        np.testing.assert_allclose(l1, l0, rtol=1e-13, atol=0)
-        np.testing.assert_allclose(a1, a0, rtol=1e-11, atol=1e-14)
+    assert out[0][0][2]['rays_closest'] >= R * R * 4
+    for other in out[1:]:
+        for (a0, l0, s0), (a1, l1, s1) in zip(out[0], other):
+            assert s0 == s1
+            np.testing.assert_allclose(l1, l0, rtol=1e-13, atol=0)
+            np.testing.assert_allclose(a1, a0, rtol=1e-11, atol=1e-14)
 
 
 def host_camera_film(res):
