@@ -339,9 +339,10 @@ def main():
                 'limiter': 'vector-memory (L1/TA) request rate and dependent-fetch latency of per-lane node loads; '
                            'HBM carries the ray/hit streams only (DESIGN.md section 5-6)',
                 'kernel': name,
-                'kernel_note': 'closest-hit launches run k_trace_meta<false> (child words in LDS) on trees of up to ~7900 '
-                               'nodes, k_trace_pair<false> (children-pair records) on larger ones; profiles/ lists the '
-                               'symbol under full_name',
+                'kernel_note': 'closest-hit launches: level 0 (camera rays) runs k_trace_packet<false> (one walk per wave, '
+                               'scalar record loads); the other levels k_trace_meta<false> (child words in LDS) on trees of '
+                               'up to ~7900 nodes, k_trace_pair<false> / k_trace_pair_refill<false> (children-pair records) '
+                               'on larger ones; the figures here are over all of them; profiles/ lists each symbol',
                 'measured': ('2 steps after the timed region on a second context with PT_OVERLAP=0 (the kernel alone on '
                              'the GPU)' if excl is not None else 'HIP events over the timed region (single stream)'),
                 'launches': int(launches), 'avg_launch_ms': avg_ms,

@@ -25,6 +25,8 @@ struct pt_ctx {
     int n_pairs;
     int use_pair;            // PT_TRACE_PAIR: 0 never, 1 always, unset (-1) = by tree size (launch_trace)
     int shade_dynamic;       // PT_SHADE_DYNAMIC: the same for k_shade's walk over the hit list
+    int use_packet;          // PT_TRACE_PACKET: bit 0 / bit 1 = the level-0 closest-hit / any-hit launches of a render walk per wave; unset (-1) = pt_render decides
+    int packet_occ[2];
     int pair_refill;         // PT_PAIR_REFILL: k_trace_pair launches of a render refill their lanes (needs the cursors); unset (-1) = by tree size
     int trace_dynamic;       // PT_TRACE_DYNAMIC: 0 = static chunk assignment in the trace launches of a render, else (default) chunk cursors
     size_t brdf_bytes;
@@ -173,6 +175,8 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     if (const char *e = getenv("PT_OVERLAP")) c->overlap = atoi(e);
     c->trace_dynamic = -1;
     c->pair_refill = -1;
+    c->use_packet = -1;
+    if (const char *e = getenv("PT_TRACE_PACKET")) c->use_packet = atoi(e);
     if (const char *e = getenv("PT_PAIR_REFILL")) c->pair_refill = atoi(e);
     c->shade_dynamic = -1;
     if (const char *e = getenv("PT_SHADE_DYNAMIC")) c->shade_dynamic = atoi(e);
@@ -697,6 +701,14 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
     // applies) closest 40.7 -> 45.7 ms, any 20.5 -> 20.5 ms: off; head_loop (352 k nodes) closest 2.1 -> 1.4 ms, any
     // 3.3 -> 2.7 ms; 10^6-triangle soup (2 M nodes) closest 114 -> 88 ms, any 61 -> 42 ms: on for trees whose
     // child words do not fit in LDS.
+    if (seg_counts && (n_val & PT_TRACE_PACKET)) {      // coherent chunks (pt_render, level 0): one walk per wave
+        int &occ = c->packet_occ[any ? 1 : 0];
+        if (occ == 0) occ = pt_trace_packet_occupancy(any, c->stack_need);
+        const long blocks = (n_bound + PT_BLOCK - 1) / PT_BLOCK;
+        const int grid = (int)std::max<long>(1, std::min<long>(blocks, (long)c->n_cu * occ));
+        return pt_launch_trace_packet(any, c->stack_need, grid, stream, c->sc, rays, stride, seg_counts, seg, out_prim, out_t,
+                                      out_b1, out_b2, rs, counters);
+    }
     int use_pair = c->use_pair;
     if (use_pair < 0) use_pair = c->meta_stack > 0 ? 0 : 3;
     if (c->d_pairs && c->n_pairs > 0 && c->d_spill && (use_pair & (any ? 2 : 1))) {
@@ -988,6 +1000,13 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     // filled queue; the pretest launch shares q[0] with the closest-hit launch after it and stays static
     const int dyn = c->trace_dynamic != 0 ? PT_TRACE_DYNAMIC : 0;
     const int shade_dyn = c->shade_dynamic != 0 ? 1 : 0;
+    // one walk per wave (k_trace_packet) for the launches whose chunks are coherent: camera rays always (the 64 samples
+    // of a pixel); their shadow rays when there is one per vertex and the tree is small (head mesh 9.2 -> 6.9 ms; with
+    // two light samples per vertex, head_loop Direct, 2.1 -> 2.3 ms; from the random triangles of the 10^6-triangle
+    // soup 30.6 -> 81.9 ms)
+    int use_packet = c->use_packet;
+    if (use_packet < 0)
+        use_packet = 1 | ((ig->kind == PT_INTEG_PATH && c->meta_stack > 0) ? 2 : 0);
     auto hit_list = [&](int level) {
         HitList hl{};
         hl.idx = c->hit_idx; hl.count = c->d_counts + 3 * PT_CNT_BLOCK;
@@ -1012,8 +1031,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         }
         {
             StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
-            HIPCHK(c, launch_trace(c, false, nb, stream, c->q[0].rays, c->q[0].stride, c->q[0].count, c->q[0].seg, dyn,
-                                   c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
+            HIPCHK(c, launch_trace(c, false, nb, stream, c->q[0].rays, c->q[0].stride, c->q[0].count, c->q[0].seg,
+                                   dyn | ((dyn && (use_packet & 1)) ? PT_TRACE_PACKET : 0), c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
         }
         int cur = 0;
         // The any-hit (shadow) trace of level k depends only on shade(k); level k+1's closest-hit trace, hit list and
@@ -1051,7 +1070,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             {
                 StageTimer tm(c, any_stream, STAGE_TRACE_ANY);
                 HIPCHK(c, launch_trace(c, true, (long)nb * spv, any_stream, sh.rays, sh.stride, sh.count, sh.seg,
-                                       dyn, nullptr, nullptr, nullptr, nullptr, rs, cnt));
+                                       dyn | ((dyn && level == 0 && (use_packet & 2)) ? PT_TRACE_PACKET : 0), nullptr, nullptr,
+                                       nullptr, nullptr, rs, cnt));
             }
             if (ovl) {
                 HIPCHK(c, hipEventRecord(c->ev_any[sb], c->aux));

@@ -58,6 +58,7 @@ __host__ __device__ inline int pt_tile_row_y(const pt_tile &t, int row) {
 // fill; results and census do not depend on which wave traced a ray.
 #define PT_CNT_CURSOR 1
 #define PT_TRACE_DYNAMIC 1
+#define PT_TRACE_PACKET 4    // with PT_TRACE_DYNAMIC: a launch over coherent chunks (level 0 of a render) walks per wave (k_trace_packet)
 #define PT_TRACE_REFILL 2    // with PT_TRACE_DYNAMIC, k_trace_pair launches: lanes that finish take new rays (k_trace_pair_refill)
 #define PT_SEG_BLOCKS (PT_SEG / (PT_BLOCK / 64))
 
@@ -136,6 +137,11 @@ hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, co
                            long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                            double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 int pt_trace_occupancy(bool any, int stack);
+size_t pt_trace_packet_lds(int stack);
+int pt_trace_packet_occupancy(bool any, int stack);
+hipError_t pt_launch_trace_packet(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                                  long stride, const int *seg_counts, long seg, int *out_prim, double *out_t, double *out_b1,
+                                  double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 // the same trace with the first sc.n_top breadth-first nodes staged in LDS (1024-thread workgroups)
 // k_trace_meta: child/primitive words of all nodes in LDS (small trees); bytes of the table and of the whole block
 __host__ __device__ inline size_t pt_trace_meta_table_bytes(int n_nodes) { return (((size_t)n_nodes * 8) + 15) & ~(size_t)15; }

@@ -957,6 +957,159 @@ hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, co
     return launch_trace_t<false>(stack, grid, stream, sc, rays, stride, seg_counts, seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
 }
 
+// ---- coherent chunks: one walk per wave ---------------------------------------------------------------------------
+// k_trace_packet: the 64 rays of a chunk of camera rays (the 64 samples of a pixel) or of their shadow rays visit
+// nearly the same nodes.  Here the WAVE walks the tree once: a stack of (node, lane mask) entries in LDS, the node and
+// triangle records fetched with wave-uniform addresses (scalar loads: no vector-memory request at all), every lane of an
+// entry's mask testing the box with its own ray.  Each lane still makes exactly the visits of its own walk, in its own
+// order (bvh.py:322-410): lanes that disagree on dir_is_neg[axis] are split into two masks, the far child of either
+// group is stacked under the near children, and a far entry is box-tested when it is popped, with the lane's maxt of
+// that moment.  So hit / prim / t / b1 / b2 and the census are those of the per-lane kernels, bit for bit (tested).
+// An entry is dropped when none of its lanes is still walking (any hit: lanes leave at their first hit).
+// Stack depth: an interior node pops one entry and pushes at most four, the top one is popped next: <= 3 entries per
+// level of the current path.
+struct PacketEnt { int node; unsigned lo, hi; int pad; };
+// Loads through the constant address space: with a wave-uniform address they are scalar loads whatever the compiler can
+// prove about aliasing stores (the any-hit form's atomics on L made it fall back to vector loads for the triangles).
+// The scene arrays are never written while a kernel runs.
+typedef double pk_d2 __attribute__((ext_vector_type(2)));
+typedef int pk_i2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) pk_d2 *pk_cd2;
+typedef const __attribute__((address_space(4))) pk_i2 *pk_ci2;
+__device__ __forceinline__ double2 pk_load(const void *base, int i) {
+    const pk_d2 v = ((pk_cd2)(unsigned long long)base)[i];
+    return make_double2(v.x, v.y);
+}
+#ifndef PT_PACKET_WAVES
+#define PT_PACKET_WAVES 5
+#endif
+template <bool ANY>
+__global__ __launch_bounds__(PT_BLOCK, PT_PACKET_WAVES) void k_trace_packet(DScene sc, const double *__restrict__ rays, long stride,
+                                                           const int *__restrict__ seg_counts, long seg,
+                                                           int *__restrict__ out_prim, double *__restrict__ out_t,
+                                                           double *__restrict__ out_b1, double *__restrict__ out_b2,
+                                                           ShadowResolve rs, unsigned long long *counters, int cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    PacketEnt *stk = reinterpret_cast<PacketEnt *>(s_mem) + (size_t)(threadIdx.x >> 6) * cap;
+    unsigned nvis = 0, ntri = 0, nray = 0;
+    const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6);
+    const int nsub = (int)((gridDim.x * (PT_BLOCK / 64)) / PT_SEG);
+    const int region = wave % PT_SEG;
+    if (wave / PT_SEG < nsub) {
+        const int n = seg_counts[region * PT_CNT_STRIDE];
+        const long first = (long)region * seg;
+        int *cursor = const_cast<int *>(seg_counts) + region * PT_CNT_STRIDE + PT_CNT_CURSOR;
+        for (;;) {
+            const int base = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(cursor, 64) : 0);
+            if (base >= n) break;
+            const int k = base + lane;
+            const bool valid = k < n;
+            Ray r;
+            r.o = r.d = mk3(0, 0, 0); r.mint = 0.; r.maxt = 0.;
+            if (valid) r = load_ray(rays, stride, first + k);
+            const SlabRay sv = slab_ray(sc, r);
+            double b1 = 0., b2 = 0.;
+            int res = ANY ? 0 : -1;
+            unsigned long long alive = __ballot(valid);
+            // the entry being visited lives in registers (cur_node, cur_m); the others wait on the LDS stack
+            int sp = 0;
+            int cur_node = 0;
+            unsigned long long cur_m = sc.n_nodes > 0 ? alive : 0ull;
+            for (;;) {
+                if (cur_m == 0ull) {
+                    if (sp == 0) break;
+                    sp--;
+                    const PacketEnt e = stk[sp];
+                    cur_node = __builtin_amdgcn_readfirstlane(e.node);
+                    cur_m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)e.hi) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)e.lo);
+                }
+                const int node = cur_node;
+                const unsigned long long m = cur_m & alive;
+                cur_m = 0ull;
+                if (m == 0ull) continue;
+                const GNode *np = sc.nodes + node;                                       // wave-uniform: scalar loads
+                const double2 n0 = pk_load(np, 0), n1 = pk_load(np, 1), n2 = pk_load(np, 2);
+                const pk_i2 mv = ((pk_ci2)(unsigned long long)np)[6];
+                const int2 meta = make_int2(mv.x, mv.y);
+                bool hb = false;
+                if ((m >> lane) & 1ull) {
+                    nvis++;
+                    hb = sv.fast ? slab_hit<true>(n0, n1, n2, r, sv) : slab_hit<false>(n0, n1, n2, r, sv);
+                }
+                const unsigned long long hm = __ballot(hb);
+                if (hm == 0ull) continue;
+                const int nprim = meta.y & 0xFFFF;
+                if (nprim > 0) {
+                    for (int i = 0; i < nprim; i++) {
+                        const GTri *tp = sc.tris + meta.x + i;
+                        const double2 a0 = pk_load(tp, 0), a1 = pk_load(tp, 1), a2 = pk_load(tp, 2), a3 = pk_load(tp, 3),
+                                      a4 = pk_load(tp, 4);
+                        // the test runs for every lane (the others' outcome is dropped): under `if (hb)` the compiler
+                        // sinks the record's loads into the divergent block and makes them vector loads
+                        double t, u1, u2;
+                        const bool th = tri_math(a0, a1, a2, a3, a4, r, t, u1, u2);
+                        if (hb) {
+                            ntri++;
+                            if (th) {
+                                if (ANY) { res = 1; hb = false; }      // intersect_p returns at its first hit
+                                else { res = meta.x + i; b1 = u1; b2 = u2; r.maxt = t; }
+                            }
+                        }
+                    }
+                    if (ANY) alive = __ballot(valid && res == 0);
+                } else {
+                    const bool neg = (sv.negmask >> (meta.y >> 16)) & 1;         // dir_is_neg[node.axis], bvh.py:350
+                    const unsigned long long negm = __ballot(hb && neg), posm = hm & ~negm;
+                    const int c1 = node + 1, c2 = meta.x;
+                    PacketEnt p;
+                    p.pad = 0;
+                    // far children under near children; the two groups share no lane, so their order is free.  The
+                    // topmost entry stays in registers.
+                    if (posm) { p.node = c2; p.lo = (unsigned)posm; p.hi = (unsigned)(posm >> 32); stk[sp++] = p; }
+                    if (negm) { p.node = c1; p.lo = (unsigned)negm; p.hi = (unsigned)(negm >> 32); stk[sp++] = p; }
+                    if (posm) {
+                        if (negm) { p.node = c2; p.lo = (unsigned)negm; p.hi = (unsigned)(negm >> 32); stk[sp++] = p; }
+                        cur_node = c1; cur_m = posm;
+                    } else {
+                        cur_node = c2; cur_m = negm;
+                    }
+                }
+            }
+            if (valid) {
+                store_result<ANY>(out, first + k, res, r, b1, b2);
+                nray++;
+            }
+        }
+    }
+    if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
+}
+
+size_t pt_trace_packet_lds(int stack) { return (size_t)(PT_BLOCK / 64) * (size_t)(3 * stack + 8) * sizeof(PacketEnt); }
+int pt_trace_packet_occupancy(bool any, int stack) {
+    int nb = 0;
+    if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_packet<true>, PT_BLOCK, pt_trace_packet_lds(stack));
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_packet<false>, PT_BLOCK, pt_trace_packet_lds(stack));
+    return nb > 0 ? nb : 4;
+}
+// segmented input with chunk cursors only (a render's level-0 launches); `stack` = the tree's depth bound
+hipError_t pt_launch_trace_packet(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                                  long stride, const int *seg_counts, long seg, int *out_prim, double *out_t, double *out_b1,
+                                  double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
+    if (!seg_counts) return hipErrorInvalidValue;
+    grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;
+    const int cap = 3 * stack + 8;
+    if (any)
+        hipLaunchKernelGGL((k_trace_packet<true>), dim3(grid), dim3(PT_BLOCK), pt_trace_packet_lds(stack), stream, sc, rays,
+                           stride, seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, cap);
+    else
+        hipLaunchKernelGGL((k_trace_packet<false>), dim3(grid), dim3(PT_BLOCK), pt_trace_packet_lds(stack), stream, sc, rays,
+                           stride, seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, cap);
+    return hipGetLastError();
+}
+
 // =========================================================================================
 // sample streams
 // =========================================================================================

@@ -183,7 +183,8 @@ def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head
 def test_dynamic_chunk_assignment_changes_nothing(torch_cuda, golden_dir, head, kind):
     """PT_TRACE_DYNAMIC / PT_SHADE_DYNAMIC: the waves of a queue region draw their 64-ray chunks from a cursor instead
     of striding over the region; PT_PAIR_REFILL: the lanes of k_trace_pair take new rays from that cursor as they finish
-    (k_trace_pair_refill).  Which wave or lane traces a ray is not observable: per-sample radiance equal to the last bits (the shadow
+    (k_trace_pair_refill); PT_TRACE_PACKET: the level-0 launches walk the tree once per wave (k_trace_packet).  Which wave or
+    lane traces a ray, or how its node records are fetched, is not observable: per-sample radiance equal to the last bits (the shadow
     contributions are atomic adds whose order is free in both forms), census equal, on a production-stream render large
     enough that every region holds many chunks, whole and as an interleaved shard."""
     from pytracer_amd._lib import Context
@@ -191,7 +192,8 @@ def test_dynamic_chunk_assignment_changes_nothing(torch_cuda, golden_dir, head, 
     R = 512                                  # 1 M samples: 16 k chunks for 4 096 waves
     sub, spp = (0, R, 0, R), (2, 2)
     settings = [{'PT_TRACE_DYNAMIC': '0', 'PT_SHADE_DYNAMIC': '0'}, {},
-                {'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '0'}, {'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1'}]
+                {'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '0'}, {'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1'},
+                {'PT_TRACE_PACKET': '3'}, {'PT_TRACE_PACKET': '0'}]
     out = []
     for env in settings:
         env = dict(env, PT_OVERLAP='0')         # one stream: the order of the adds into L is then the launch order
