@@ -20,7 +20,7 @@ struct pt_ctx {
     // scene (device)
     bool have_scene;
     DScene sc;
-    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf;
+    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf, *d_tri_cls;
     void *d_pairs;           // GPair records of the interior nodes (k_trace_pair)
     int n_pairs;
     int use_pair;            // PT_TRACE_PAIR: 0 never, 1 always, unset (-1) = by tree size (launch_trace)
@@ -240,7 +240,7 @@ static void collect_timing(pt_ctx *c, pt_stats *stats) {
 
 static void free_scene(pt_ctx *c) {
     void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top,
-                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill};
+                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill, &c->d_tri_cls};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -629,6 +629,16 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     rc = upload_brdf_tables(c, d, mats);
     if (rc != PT_OK) return rc;
     HIPCHK(c, upload(&c->d_mats, mats.data(), mats.size()));
+    if (c->d_brdf && d->n_tris > 0 && !getenv("PT_NO_HIT_CLASSES")) {
+        // per triangle: does its material carry a measured lobe?  k_list_hits lists those hits apart (pt_kernels.h HitList)
+        std::vector<unsigned char> cls((size_t)d->n_tris, 0);
+        for (int i = 0; i < d->n_tris; i++) {
+            const pt_material &m = mats[(size_t)d->tri_mat[i]];
+            for (int l = 0; l < m.n_lobes; l++)
+                if (m.lobes[l].type == PT_LOBE_MEASURED_IRISO) cls[(size_t)i] = 1;
+        }
+        HIPCHK(c, upload(&c->d_tri_cls, cls.data(), cls.size()));
+    }
     HIPCHK(c, upload(&c->d_lights, d->lights, (size_t)d->n_lights));
     if (d->n_textures > 0) {
         HIPCHK(c, upload(&c->d_tex, d->textures, (size_t)d->n_textures));
@@ -1013,6 +1023,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
         hl.esc = c->st.esc;
         hl.add_escape = level > 0;
         hl.dynamic = shade_dyn;
+        hl.tri_cls = (const unsigned char *)c->d_tri_cls;
         return hl;
     };
     c->ev_used = 0;

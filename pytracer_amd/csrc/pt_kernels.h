@@ -91,7 +91,12 @@ struct HitList {
     int *esc;          // PathState::esc
     int add_escape;    // level > 0: a miss marks its path escaped (esc[slot] = 1); k_splat adds T * Σ light.le for it
     int dynamic;       // k_shade draws its 64-entry chunks from the region's cursor (PT_CNT_CURSOR) instead of striding
+    // Scenes with measured BRDF lobes: hits on such materials are listed from the FRONT of the region, the others from
+    // its BACK (second counter: element PT_CNT_BACK of the region's line), so that a shading wave holds one class only
+    // (the table walk of a measured lobe costs 5x a plain vertex and a wave pays its most expensive lane).  nullptr = one list.
+    const unsigned char *tri_cls;   // [n_tris] 1 = the triangle's material has a measured lobe
 };
+#define PT_CNT_BACK 2
 
 struct ShadowResolve {
     const double *c;

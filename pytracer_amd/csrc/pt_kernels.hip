@@ -1405,8 +1405,12 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
     const int nsub = (int)((gridDim.x * (PT_BLOCK / 64)) / PT_SEG);
     const int region = wave % PT_SEG, sub = wave / PT_SEG;
     if (sub >= nsub) return;
-    const int n = hl.count[region * PT_CNT_STRIDE];     // the entries of this region whose ray hit something (list_hit)
-    const int nloop = (n + 63) & ~63;   // whole waves stay convergent for the ballots
+    // the region's hits (k_list_hits): n_front listed from the region's start, n_back from its end (scenes with measured
+    // lobes: front = hits on such materials).  The loop runs over a virtual index: the front list padded to whole chunks,
+    // then the back list, so that no chunk mixes the two.
+    const int n_front = hl.count[region * PT_CNT_STRIDE], n_back = hl.count[region * PT_CNT_STRIDE + PT_CNT_BACK];
+    const int n_fpad = (n_front + 63) & ~63;
+    const int nloop = n_fpad + ((n_back + 63) & ~63);   // whole waves stay convergent for the ballots
     const long first = (long)region * qin.seg;
     // chunk kb of the region's hit list: the static stride, or (hl.dynamic) the next claim on the region's cursor — a
     // claim when needed, held in a scalar register: this kernel has no VGPR to carry a claim across the vertex code
@@ -1417,8 +1421,9 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
     };
     for (int kb = hl.dynamic ? next_chunk(0) : sub * 64; kb < nloop; kb = next_chunk(kb)) {
         const int k = kb + lane;
-        const bool live = k < n;
-        const long i = first + (live ? hl.idx[first + k] : 0);
+        const bool is_back = k >= n_fpad;
+        const bool live = is_back ? (k - n_fpad < n_back) : (k < n_front);
+        const long i = first + (live ? hl.idx[is_back ? first + qin.seg - 1 - (k - n_fpad) : first + k] : 0);
         int slot = 0, prim = -1;
         if (live) { slot = qin.slot[i]; prim = qin.prim[i]; }
         const long P = st.stride, S = qin.stride;
@@ -1598,25 +1603,38 @@ __global__ __launch_bounds__(PT_BLOCK) void k_list_hits(Queue q, HitList hl) {
             const int k = kb + u * 64 + lane;
             prim[u] = k < n ? q.prim[first + k] : 0;          // 0: past the end counts neither as a hit nor as an escape
         }
-        unsigned long long mask[PT_LIST_UNROLL];
-        int total = 0;
+        unsigned long long mask[PT_LIST_UNROLL], back[PT_LIST_UNROLL];
+        int total = 0, total_b = 0;
 #pragma unroll
         for (int u = 0; u < PT_LIST_UNROLL; u++) {
             const int k = kb + u * 64 + lane;
             const bool live = k < n;
             if (live && prim[u] < 0 && hl.add_escape) hl.esc[q.slot[first + k]] = 1;
-            mask[u] = __ballot(live && prim[u] >= 0);
+            const bool hit = live && prim[u] >= 0;
+            const bool front = hit && (!hl.tri_cls || hl.tri_cls[prim[u]] != 0);
+            mask[u] = __ballot(front);
+            back[u] = __ballot(hit && !front);
             total += __popcll(mask[u]);
+            total_b += __popcll(back[u]);
         }
-        if (total == 0) continue;                             // wave-uniform
-        int base = 0;
-        if (lane == 0) base = atomicAdd(hl.count + region * PT_CNT_STRIDE, total);
+        if (total + total_b == 0) continue;                   // wave-uniform
+        int base = 0, base_b = 0;
+        if (lane == 0) {
+            if (total) base = atomicAdd(hl.count + region * PT_CNT_STRIDE, total);
+            if (total_b) base_b = atomicAdd(hl.count + region * PT_CNT_STRIDE + PT_CNT_BACK, total_b);
+        }
         base = __shfl(base, 0);
+        base_b = __shfl(base_b, 0);
+        const long last = first + q.seg - 1;                  // the back list grows downwards from the region's end
 #pragma unroll
         for (int u = 0; u < PT_LIST_UNROLL; u++) {
             const int k = kb + u * 64 + lane;
-            if (k < n && prim[u] >= 0) hl.idx[first + base + (int)lane_prefix(mask[u])] = k;
+            if (k < n && prim[u] >= 0) {
+                if ((mask[u] >> lane) & 1ull) hl.idx[first + base + (int)lane_prefix(mask[u])] = k;
+                else hl.idx[last - (base_b + (int)lane_prefix(back[u]))] = k;
+            }
             base += __popcll(mask[u]);
+            base_b += __popcll(back[u]);
         }
     }
 }
