@@ -20,7 +20,7 @@ struct pt_ctx {
     // scene (device)
     bool have_scene;
     DScene sc;
-    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf, *d_tri_cls;
+    void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf, *d_tri_cls, *d_frames;
     void *d_pairs;           // GPair records of the interior nodes (k_trace_pair)
     int n_pairs;
     int use_pair;            // PT_TRACE_PAIR: 0 never, 1 always, unset (-1) = by tree size (launch_trace)
@@ -240,7 +240,7 @@ static void collect_timing(pt_ctx *c, pt_stats *stats) {
 
 static void free_scene(pt_ctx *c) {
     void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top,
-                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill, &c->d_tri_cls};
+                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill, &c->d_tri_cls, &c->d_frames};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -658,6 +658,7 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     s.tri_verts = (const double *)c->d_verts;
     s.tri_mat = (const int32_t *)c->d_mat;
     s.tri_flip = (const int32_t *)c->d_flip;
+    s.tri_frames = nullptr;
     s.mats = (const pt_material *)c->d_mats;
     s.lights = (const pt_light *)c->d_lights;
     s.textures = (const pt_texture *)c->d_tex;
@@ -667,6 +668,13 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     s.brdf_lds_bytes = (c->d_brdf && c->brdf_bytes + PT_MEAS_HITS * PT_BLOCK * sizeof(int) <= (size_t)PT_MEAS_LDS_MAX && !getenv("PT_BRDF_NO_LDS")) ? (int32_t)c->brdf_bytes : 0;
     s.n_nodes = d->n_nodes; s.n_tris = d->n_tris; s.n_mats = d->n_materials; s.n_lights = d->n_lights;
     memcpy(s.le_sum, le, sizeof(le));
+    if (d->n_tris > 0) {
+        // the shading frame of every triangle, by the device code a per-hit evaluation would run (pt_device.h tri_frame)
+        HIPCHK(c, hipMalloc(&c->d_frames, 9 * (size_t)d->n_tris * sizeof(double)));
+        HIPCHK(c, pt_launch_tri_frames(nullptr, s, (double *)c->d_frames));
+        HIPCHK(c, hipStreamSynchronize(nullptr));
+        s.tri_frames = (const double *)c->d_frames;
+    }
     c->stack_need = std::max(depth, 1);
     c->trace_occ[0] = c->trace_occ[1] = 0;
     c->pair_occ[0] = c->pair_occ[1] = 0;

@@ -136,12 +136,13 @@ struct BrdfGrid {
 
 struct DScene {
     const GNode *nodes;
-    const GPair *pairs;        // one record per interior node, numbered in depth-first order (root = 0), or nullptr
-    const TopNode *top;        // the first n_top nodes in breadth-first order, or nullptr
+    const GPair *pairs;        // one record per interior node, numbered in depth-first order (root = 0), (k_tri_frames at upload)
+    const TopNode *top;        // the first n_top nodes in breadth-first order, (k_tri_frames at upload)
     int32_t n_top;
     int32_t exact_slab;        // a node box with min > max (or NaN): only the reference's own comparison order is exact
     const GTri *tris;
     const double *tri_verts;   // [n_tris][9] p1,p2,p3 for shading geometry
+    const double *tri_frames;  // [n_tris][9] nn, sn, tn: the shading frame of every triangle (tri_frame), (k_tri_frames at upload)
     const int32_t *tri_mat;
     const int32_t *tri_flip;
     const pt_material *mats;
@@ -174,9 +175,13 @@ struct Vertex {
     int *hits;                 // this thread's hit list in LDS (measured_f; k_shade<KIND, 2> only)
 };
 
-// EXT: the scene has textures or mesh uvs (k_shade<KIND, true>); without it the default uvs are compile-time constants
+// The shading frame of a triangle: nn, sn, tn of BSDF.__init__ from dpdu, dpdv of Triangle.intersect.  It depends on the
+// triangle only (vertices, uvs, orientation flag): pt_scene_upload runs this once per triangle ON THE DEVICE
+// (k_tri_frames: the same instructions as a per-hit evaluation would execute, so the same bits) and make_vertex reads the
+// 72-byte result instead of 72 bytes of vertices + 8 divisions and 2 square roots per hit.
+// EXT: the scene may have mesh uvs; without them the default uvs are compile-time constants (same arithmetic).
 template <bool EXT>
-__device__ inline void make_vertex(const DScene &sc, const Ray &r, int prim, double t, Vertex &vx) {
+__device__ inline void tri_frame(const DScene &sc, int prim, d3 &nn, d3 &sn, d3 &tn) {
     const double *tv = sc.tri_verts + 9 * (size_t)prim;
     d3 p1 = mk3(tv[0], tv[1], tv[2]), p2 = mk3(tv[3], tv[4], tv[5]), p3 = mk3(tv[6], tv[7], tv[8]);
     d3 dpdu, dpdv;
@@ -212,12 +217,18 @@ __device__ inline void make_vertex(const DScene &sc, const Ray &r, int prim, dou
         dpdu = ((dp1 * dv2) - (dp2 * dv1)) * detInv;
         dpdv = ((dp1 * (-du2)) + (dp2 * du1)) * detInv;
     }
+    nn = normalize3(cross3(dpdu, dpdv));
+    if (sc.tri_flip[prim]) nn = nn * -1.0;
+    sn = normalize3(dpdu);
+    tn = cross3(nn, sn);
+}
+
+template <bool EXT>
+__device__ inline void make_vertex(const DScene &sc, const Ray &r, int prim, double t, Vertex &vx) {
+    const double *f = sc.tri_frames + 9 * (size_t)prim;
+    vx.nn = mk3(f[0], f[1], f[2]); vx.sn = mk3(f[3], f[4], f[5]); vx.tn = mk3(f[6], f[7], f[8]);
     vx.p = r.o + r.d * t;
-    vx.nn = normalize3(cross3(dpdu, dpdv));
-    if (sc.tri_flip[prim]) vx.nn = vx.nn * -1.0;
     vx.rEps = 1e-3 * t;
-    vx.sn = normalize3(dpdu);
-    vx.tn = cross3(vx.nn, vx.sn);
     vx.mat = sc.mats + sc.tri_mat[prim];
     vx.brdf = sc.brdf;
     vx.hits = nullptr;

@@ -142,6 +142,8 @@ hipError_t pt_launch_trace(bool any, int stack, int grid, hipStream_t stream, co
                            long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                            double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 int pt_trace_occupancy(bool any, int stack);
+// fills frames[n_tris][9] with the shading frame of every triangle (sc.tri_frames must still be nullptr)
+hipError_t pt_launch_tri_frames(hipStream_t stream, const DScene &sc, double *frames);
 size_t pt_trace_packet_lds(int stack);
 int pt_trace_packet_occupancy(bool any, int stack);
 hipError_t pt_launch_trace_packet(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,

@@ -1110,6 +1110,21 @@ hipError_t pt_launch_trace_packet(bool any, int stack, int grid, hipStream_t str
     return hipGetLastError();
 }
 
+// The shading frames of all triangles, once per scene upload (pt_device.h tri_frame).
+__global__ __launch_bounds__(PT_BLOCK) void k_tri_frames(DScene sc, double *__restrict__ frames) {
+    const int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= sc.n_tris) return;
+    d3 nn, sn, tn;
+    tri_frame<true>(sc, i, nn, sn, tn);
+    double *f = frames + 9 * (size_t)i;
+    f[0] = nn.x; f[1] = nn.y; f[2] = nn.z; f[3] = sn.x; f[4] = sn.y; f[5] = sn.z; f[6] = tn.x; f[7] = tn.y; f[8] = tn.z;
+}
+hipError_t pt_launch_tri_frames(hipStream_t stream, const DScene &sc, double *frames) {
+    if (sc.n_tris <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tri_frames, dim3((sc.n_tris + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, stream, sc, frames);
+    return hipGetLastError();
+}
+
 // =========================================================================================
 // sample streams
 // =========================================================================================
