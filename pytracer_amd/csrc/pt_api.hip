@@ -1023,8 +1023,10 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     // two light samples per vertex, head_loop Direct, 2.1 -> 2.3 ms; from the random triangles of the 10^6-triangle
     // soup 30.6 -> 81.9 ms)
     int use_packet = c->use_packet;
+    // ... and only for launches that give every resident wave several chunks: a chunk's per-wave walk is one serial chain
+    // (~25 us against ~10 us for 64 per-lane walks side by side), which a 16 k-ray launch cannot hide (C1: 0.49 vs 0.54 ms)
     if (use_packet < 0)
-        use_packet = 1 | ((ig->kind == PT_INTEG_PATH && c->meta_stack > 0) ? 2 : 0);
+        use_packet = std::min(batch, total) >= (1l << 20) ? (1 | ((ig->kind == PT_INTEG_PATH && c->meta_stack > 0) ? 2 : 0)) : 0;
     auto hit_list = [&](int level) {
         HitList hl{};
         hl.idx = c->hit_idx; hl.count = c->d_counts + 3 * PT_CNT_BLOCK;
