@@ -336,8 +336,10 @@ def main():
                 # what the HBM actually carries: the tree is cache-resident, so this is far below `frac`, which prices
                 # every node / triangle byte as if streamed.  The real limiter is named here.
                 'hbm_traffic_frac': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
-                'limiter': 'vector-memory (L1/TA) request rate and dependent-fetch latency of per-lane node loads; '
-                           'HBM carries the ray/hit streams only (DESIGN.md section 5-6)',
+                'limiter': 'the dependent chain of a visit (record fetch from L1/L2 -> binary64 slab test -> stack -> next '
+                           'fetch, plus a triangle block in most steps of a divergent wave), not the number of requests '
+                           '(a 16-byte-node form with a third of them runs as fast); HBM carries the ray/hit streams only '
+                           '(DESIGN.md section 5-6)',
                 'kernel': name,
                 'kernel_note': 'closest-hit launches: level 0 (camera rays) runs k_trace_packet<false> (one walk per wave, '
                                'scalar record loads); the other levels k_trace_meta<false> (child words in LDS) on trees of '
