@@ -26,6 +26,14 @@ t(64 spp) / (K t(64/K spp)), the efficiency an N = K run can reach before the fi
 
 Prints ONE JSON line on rank 0 (see the driver contract); extra keys: `roofline` for the
 dominant kernel and `cpu_baseline` (the CPU oracle timed on this box's host, rank 0, N=1 only).
+
+`roofline` (N = 1): the top-level achieved / frac / avg_launch_ms are HIP events around the dominant stage's
+launches INSIDE the timed region (pt_set_profiling level 2: only the trace launches are bracketed), i.e. the
+configuration `value` is quoted on — two streams, kernels sharing the machine.  `roofline.exclusive` is the same
+kernel alone on the GPU (two steps after the timed region on a second context with PT_OVERLAP=0), and
+`roofline.per_symbol` / `roofline.per_launch` price every traversal kernel symbol and every launch of one such step
+by its OWN census (pt_launch_log: rays, node visits, triangle tests and ms per launch).
+N > 1: no events in the timed region (none of this is needed there; `collective` says what RCCL saw).
 """
 import argparse
 import json
@@ -185,7 +193,8 @@ def main():
         wname = '10^6-triangle soup %dx%d, %d spp, %s max_depth 5, spot + sphere lights (BASELINE.json configs[3])'
     ctx = Context(dev.index)
     ctx.upload(flat)
-    ctx.set_profiling(True)
+    # N = 1: HIP events around the trace launches of the timed region (the roofline's live figure); N > 1: none
+    ctx.set_profiling(2 if world == 1 else 0)
     integ = pa.integrator_desc(kind, 5, pretest=False, shade_f32=args.shade_f32)
     ys = xs if ys is None else ys
     from pytracer_amd.renderer import shard_tile
@@ -200,11 +209,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(stats, t=None):
+    reduce_ev = []                              # (start, end) CUDA events around every film reduce of the timed region
+
+    def step(stats, t=None, timed=False):
         acc.zero_()
         ctx.render(cam, film, smp, integ, tile if t is None else t, acc, stats=stats)
         if dist is not None:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.reduce(acc, dst=0)             # RCCL sum of film accumulators over xGMI
+            if timed:
+                e1.record()
+                reduce_ev.append((e0, e1))
         return ctx.film_resolve(acc)
 
     for _ in range(args.warmup):
@@ -213,7 +230,7 @@ def main():
     st = A.pt_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rgb = step(st)
+        rgb = step(st, timed=True)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -223,7 +240,16 @@ def main():
         cnt = torch.tensor([st.rays_closest + st.rays_any, st.camera_samples], dtype=torch.float64, device=dev)
         dist.all_reduce(cnt)
         rays_total, samples_total = float(cnt[0].item()), float(cnt[1].item())
+        # what the collective saw, from this process: backend, world size, and the time of the film reduce as the
+        # render stream saw it (events on the current stream around dist.reduce; max over ranks)
+        rms = torch.tensor([sum(a.elapsed_time(b) for a, b in reduce_ev) / max(len(reduce_ev), 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(rms, op=dist.ReduceOp.MAX)
+        collective = {'op': 'reduce(sum) of the f64 film accumulators to rank 0', 'backend': dist.get_backend(),
+                      'world_size': dist.get_world_size(), 'bytes': acc.numel() * 8,
+                      'reduce_ms_per_step_max_over_ranks': float(rms.item()),
+                      'devices': torch.cuda.device_count(), 'device_name': torch.cuda.get_device_name(dev)}
     else:
+        collective = None
         rays_total, samples_total = float(st.rays_closest + st.rays_any), float(st.camera_samples)
 
     # N > 1, strong scaling: the same job on one rank, outside the timed region, for the checksum comparison
@@ -238,6 +264,7 @@ def main():
     if world == 1 and args.shard_of:
         proxy = {}
         t_full = None
+        ctx.set_profiling(0)                    # as a rank of an N > 1 run renders: no events around the launches
         for K in sorted(set([1] + [int(k) for k in args.shard_of.split(',') if k.strip()])):
             tk = shard_tile(smp, 0, K, args.shard_mode)
             step(A.pt_stats(), tk)
@@ -251,8 +278,7 @@ def main():
             if K == 1:
                 t_full = ms
             proxy[str(K)] = {'ms_per_step': ms, 'spp_per_shard': tk.s1 - tk.s0, 'rows_per_shard': tk.rows(),
-                             'predicted_efficiency': t_full / (K * ms),
-                             'stage_ms_per_step': {k: v / args.steps for k, v in stk.timing().items()}}
+                             'predicted_efficiency': t_full / (K * ms)}
         # the reduce itself cannot be timed on one GPU: its on-device half (acc += other, 32 MiB f64) can
         other = torch.ones_like(acc)
         acc.add_(other)                         # first use loads torch's kernel: not part of the figure
@@ -272,15 +298,19 @@ def main():
     # (PT_OVERLAP, default on), so per-kernel durations of the timed region include the slow-down of sharing the
     # machine.  For the roofline of the kernel BY ITSELF, two extra steps on a second context with the overlap off
     # (outside the timed region).
-    excl = None
-    if rank == 0 and world == 1 and os.environ.get('PT_OVERLAP', '1') != '0':
+    excl, excl_log = None, None
+    if rank == 0 and world == 1:
+        prev = os.environ.get('PT_OVERLAP')
         os.environ['PT_OVERLAP'] = '0'
         try:
             cx = Context(dev.index)
         finally:
-            del os.environ['PT_OVERLAP']
+            if prev is None:
+                del os.environ['PT_OVERLAP']
+            else:
+                os.environ['PT_OVERLAP'] = prev
         cx.upload(flat)
-        cx.set_profiling(True)
+        cx.set_profiling(1)
         accx = torch.zeros_like(acc)
         cx.render(cam, film, smp, integ, tile, accx, stats=A.pt_stats())
         excl = A.pt_stats()
@@ -288,18 +318,17 @@ def main():
             accx.zero_()
             cx.render(cam, film, smp, integ, tile, accx, stats=excl)
         torch.cuda.synchronize()
+        excl_log = cx.launch_log()              # every launch of the last of these steps, with its own census
         cx.close()
         del accx
 
     if rank == 0:
-        # Dominant kernel: whichever of the two traversal kernels takes more time BY ITSELF.  With the render's two
-        # streams (PT_OVERLAP, default) HIP-event durations inside the timed region include the time a kernel spends
-        # queued behind, or sharing CUs with, the other stream's kernels (the any-hit launches read 3x "longer" than
-        # alone while the step gets shorter), so they cannot price a kernel against a roofline.  The roofline is
-        # therefore taken from the two steps run right after the timed region on a second context with the overlap off
-        # (`excl`: same process, same inputs, same launches — these durations are what rocprofv3 --kernel-trace reports
-        # for the command, profiles/); the timed region's own event figures are kept under `timed_region`.
-        def per_kernel(stt, steps):
+        # Dominant kernel: whichever of the two traversal stages takes more time BY ITSELF (the exclusive steps; the
+        # timed region's own events when there are none).  Top-level figures: HIP events over the timed region, on
+        # the stream each kernel is launched on — with the render's two streams (PT_OVERLAP, default) those durations
+        # include the time a kernel shares the machine with the other stream's kernels; `exclusive` prices the
+        # kernel alone (what rocprofv3 --kernel-trace reports for the one-stream command, profiles/).
+        def per_kernel(stt):
             n_any, n_clo = stt.rays_any, stt.rays_closest
             nv_any, nt_any = stt.node_visits_any, stt.tri_tests_any
             nv_clo, nt_clo = stt.node_visits - nv_any, stt.tri_tests - nt_any
@@ -309,58 +338,89 @@ def main():
                 'k_trace<any>': (stt.ms_trace_any, stt.launches_trace_any, algorithmic_bytes(n_any, nv_any, nt_any),
                                  n_any, nv_any, nt_any),
             }
-        src, src_steps = (excl, 2) if excl is not None else (st, args.steps)
-        cand = per_kernel(src, src_steps)
-        name = max(cand, key=lambda k: cand[k][0])
-        ms, launches, abytes, nr, nv, nt = cand[name]
-        achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+        def figures(stt, steps, name):
+            ms, launches, abytes, nr, nv, nt = per_kernel(stt)[name]
+            ach = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'launches': int(launches),
+                    'avg_launch_ms': ms / max(launches, 1), 'algorithmic_bytes_per_launch': abytes / max(launches, 1),
+                    'rays': int(nr), 'node_visits_per_ray': nv / max(nr, 1), 'tri_tests_per_ray': nt / max(nr, 1),
+                    'kernel_Mrays_per_s': nr / (ms * 1e-3) / 1e6 if ms > 0 else 0.0,
+                    'stage_ms_per_step': {k: v / steps for k, v in stt.timing().items()}}
+        pick = per_kernel(excl if excl is not None else st)
+        name = max(pick, key=lambda k: pick[k][0])
+        live = figures(st, args.steps, name)
         # `traffic` is NOT measured by this run: PMC counters need rocprofv3 passes of their own.  It is the recorded
-        # figure of profiles/pmc_summary.json (2 x FETCH_SIZE + WRITE_SIZE per launch of this kernel on the headline
-        # workload), valid for the commit named there; other workloads / sizes get null.
-        traffic, traffic_source = None, None
+        # figure of profiles/pmc_summary.json (2 x FETCH_SIZE + WRITE_SIZE per launch, summed over every kernel
+        # symbol of this stage on the headline workload), valid for the commit named there; other workloads get null.
+        traffic, traffic_source, traffic_sym = None, None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
         headline = args.workload == 'head' and res == 1024 and xs * ys == 64 and kind == A.PT_INTEG_PATH and world == 1
         if os.path.exists(pmc) and headline:
             try:
                 pj = json.load(open(pmc))
                 traffic = pj.get(name, {}).get('hbm_bytes_per_launch')
+                traffic_sym = {k: {'launches': v.get('launches'), 'hbm_bytes_per_launch': v.get('hbm_bytes_per_launch')}
+                               for k, v in pj.get('_symbols', {}).items() if v.get('stage') == name}
                 meta = pj.get('_meta', {})
                 traffic_source = {'file': 'profiles/pmc_summary.json', 'csv': pj.get(name, {}).get('source'),
                                   'commit': meta.get('commit'), 'recorded': meta.get('recorded'),
-                                  'note': 'recorded rocprofv3 --pmc passes, not measured in this run'}
+                                  'note': 'recorded rocprofv3 --pmc passes (one stream), not measured in this run'}
             except Exception:
                 traffic = None
-        avg_ms = ms / max(launches, 1)
-        roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
-                # what the HBM actually carries: the tree is cache-resident, so this is far below `frac`, which prices
-                # every node / triangle byte as if streamed.  The real limiter is named here.
-                'hbm_traffic_frac': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
-                'limiter': 'the dependent chain of a visit (record fetch from L1/L2 -> binary64 slab test -> stack -> next '
-                           'fetch, plus a triangle block in most steps of a divergent wave), not the number of requests '
-                           '(a 16-byte-node form with a third of them runs as fast); HBM carries the ray/hit streams only '
-                           '(DESIGN.md section 5-6)',
-                'kernel': name,
-                'kernel_note': 'closest-hit launches: level 0 (camera rays) runs k_trace_packet<false> (one walk per wave, '
-                               'scalar record loads); the other levels k_trace_meta<false> (child words in LDS) on trees of '
-                               'up to ~7900 nodes, k_trace_pair<false> / k_trace_pair_refill<false> (children-pair records) '
-                               'on larger ones; the figures here are over all of them; profiles/ lists each symbol',
-                'measured': ('2 steps after the timed region on a second context with PT_OVERLAP=0 (the kernel alone on '
-                             'the GPU)' if excl is not None else 'HIP events over the timed region (single stream)'),
-                'launches': int(launches), 'avg_launch_ms': avg_ms,
-                'algorithmic_bytes_per_launch': abytes / max(launches, 1),
-                'rays': int(nr), 'node_visits_per_ray': nv / max(nr, 1), 'tri_tests_per_ray': nt / max(nr, 1),
-                'kernel_Mrays_per_s': nr / (ms * 1e-3) / 1e6 if ms > 0 else 0.0,
-                'stage_ms_per_step': {k: v / src_steps for k, v in src.timing().items()}}
+        roof = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': name}
+        if world > 1:                           # no events in an N > 1 timed region: the roofline is an N = 1 figure
+            live = {k: (None if k in ('achieved', 'frac', 'avg_launch_ms') else v) for k, v in live.items()}
+            live['stage_ms_per_step'] = None
+        roof.update(live)
+        roof.update({
+            'measured': 'HIP events around every launch of this stage inside the timed region, on the stream it is launched '
+                        'on' + (' (two streams: the durations include sharing the machine with the other stream\'s kernels; '
+                                'see `exclusive`)' if os.environ.get('PT_OVERLAP', '1') != '0' else ' (one stream)'),
+            'traffic': traffic, 'traffic_per_symbol': traffic_sym, 'traffic_source': traffic_source,
+            # `frac` prices every node / triangle byte as if streamed from HBM.  The tree is
+            # cache-resident: what the HBM actually carries per launch is `traffic`, and the measured limiter is below.
+            'bound_measured': 'cache latency: L1/L2-resident tree, dependent fetch chain per visit (not HBM bandwidth)',
+            'limiter': 'the dependent chain of a visit (record fetch from L1/L2 -> binary64 slab test -> stack -> next '
+                       'fetch, plus a triangle block in most steps of a divergent wave), not the number of requests '
+                       '(a 16-byte-node form with a third of them runs as fast); HBM carries the ray/hit streams only; '
+                       'the level-0 launches (k_trace_packet) are binary64-VALU-bound (DESIGN.md section 5-6)',
+        })
         if excl is not None:
-            t_ms, t_launches, t_bytes = per_kernel(st, args.steps)[name][:3]
-            roof['timed_region'] = {
-                'note': 'HIP events around the same launches inside the timed region, where the any-hit traces run on a '
-                        'second stream beside closest-hit traces and shading: durations include queueing / sharing',
-                'achieved': t_bytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0,
-                'frac': (t_bytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ms > 0 else 0.0,
-                'avg_launch_ms': t_ms / max(t_launches, 1),
-                'stage_ms_per_step': {k: v / args.steps for k, v in st.timing().items()}}
+            ex = figures(excl, 2, name)
+            ex['measured'] = ('2 steps after the timed region on a second context with PT_OVERLAP=0 (every kernel alone on '
+                              'the GPU, every launch timed)')
+            ex['hbm_traffic_frac'] = (traffic / (ex['avg_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and ex['avg_launch_ms'] > 0) else None
+            roof['exclusive'] = ex
+            # every trace launch of ONE exclusive step, priced by its own census, and the same per kernel symbol
+            per_launch, per_symbol = [], {}
+            for r in excl_log:
+                if not r['stage'].startswith('trace') or r['ms'] <= 0 or r['rays'] == 0:
+                    continue
+                b = algorithmic_bytes(r['rays'], r['node_visits'], r['tri_tests'])
+                sym = '%s<%s>' % (r['kernel'], 'true' if r['stage'] == 'trace_any' else 'false')
+                e = {'symbol': sym, 'level': r['level'], 'batch': r['batch'], 'rays': r['rays'],
+                     'node_visits_per_ray': r['node_visits'] / r['rays'], 'tri_tests_per_ray': r['tri_tests'] / r['rays'],
+                     'B_ray': b / r['rays'], 'ms': r['ms'], 'Grays_per_s': r['rays'] / r['ms'] / 1e6,
+                     'achieved': b / r['ms'] / 1e6, 'frac': b / r['ms'] / 1e6 / HBM_PEAK_GBS}
+                per_launch.append(e)
+                a = per_symbol.setdefault(sym, {'launches': 0, 'rays': 0, 'bytes': 0.0, 'ms': 0.0})
+                a['launches'] += 1; a['rays'] += r['rays']; a['bytes'] += b; a['ms'] += r['ms']
+            for sym, a in per_symbol.items():
+                a['B_ray'] = a['bytes'] / max(a['rays'], 1)
+                a['avg_launch_ms'] = a['ms'] / a['launches']
+                a['Grays_per_s'] = a['rays'] / a['ms'] / 1e6
+                a['achieved'] = a['bytes'] / a['ms'] / 1e6
+                a['frac'] = a['achieved'] / HBM_PEAK_GBS
+                a['bound_measured'] = ('binary64 VALU issue (one walk per wave, scalar record loads)' if sym.startswith('k_trace_packet')
+                                       else 'latency + L2 misses (tree beyond the L2)' if flat.n_nodes >= (1 << 18)
+                                       else 'L1/L2 latency chain per visit')
+                del a['bytes']
+            roof['per_symbol'] = per_symbol
+            if len(per_launch) > 64:                       # many wavefront batches (C4 at 256 spp): first batch only
+                per_launch = [e for e in per_launch if e['batch'] == 0]
+            roof['per_launch'] = per_launch
+            roof['per_launch_note'] = 'one exclusive step (PT_OVERLAP=0), each launch with its own census (pt_launch_log)'
         out = {
             'metric': 'Mrays/s', 'value': rays_total / dt / 1e6, 'unit': 'Mrays/s',
             'samples_per_s': samples_total / dt,
@@ -384,6 +444,8 @@ def main():
             assert out['config']['checksum_rel_diff'] <= 1e-9, 'the sharded film differs from the 1-rank film: %r' % out['config']
         if proxy is not None:
             out['shard_proxy'] = proxy
+        if collective is not None:
+            out['collective'] = collective
         if world == 1 and not args.no_cpu_baseline and args.workload == 'head':
             out['cpu_baseline'] = cpu_baseline(flat, cam, film, integ, res, xs)
         print(json.dumps(out))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 11
+#define PT_ABI_VERSION 12
 
 typedef enum {
     PT_OK = 0,
@@ -255,10 +255,14 @@ int pt_intersect(pt_ctx *ctx, const double *rays, int64_t n, int any_hit,
  *   stats  NULL: the call enqueues a memset of the scratch and the trace kernel on `stream` and returns
  *          without synchronising (capturable).  Non-NULL: it then copies the 20 KB of counters to the host
  *          stack and synchronises `stream`, like pt_intersect.
- * All calls on one GPU share that GPU's array, which keeps the last call's sums (every call clears it first):
- * two pt_intersect_static calls that overlap on one GPU — different streams or different contexts of the
- * same device — race on the census (the hit records stay correct).  Serialise them, or pass stats == NULL
- * on all but one. */
+ * All calls on one GPU share that GPU's array, which keeps the last call's sums (every call clears it first).
+ * Overlap: like every entry point, calls on ONE context must be serialised by the caller — one stream at a
+ * time, and not concurrently with pt_render / pt_intersect on that context: the traversal kernels of large
+ * trees keep their todo stacks in a per-context spill area indexed by grid thread, so two launches of one
+ * context in flight together would corrupt each other's walks (wrong hit records, not only a wrong census).
+ * Calls on DIFFERENT contexts of the same GPU may overlap: each context has its own spill area, so the hit
+ * records are correct, and only the census — the one thing in the shared array — races; pass stats == NULL on
+ * all but one of them, or serialise them. */
 #define PT_INTERSECT_STATIC_MAX_RAYS 0x40000000LL
 int pt_intersect_static(pt_ctx *ctx, const double *rays, int64_t n, int any_hit,
                         int32_t *prim, double *t, double *b1, double *b2,
@@ -279,9 +283,34 @@ int pt_render(pt_ctx *ctx, const pt_camera *cam, const pt_film_desc *film,
               double *film_accum, double *sample_L, pt_stats *stats, void *stream);
 
 /* No counterpart in the reference (it has no timers): measurement hook for
- * bench.py.  When enabled, pt_render / pt_intersect bracket every kernel launch with HIP events
- * on the caller's stream and add the per-stage totals to pt_stats (requires stats != NULL). */
+ * bench.py.  enable = 1: pt_render / pt_intersect bracket every kernel launch with HIP events on the
+ * stream it is launched on and add the per-stage totals to pt_stats (requires stats != NULL); every
+ * trace launch counts its rays, node visits and triangle tests into a census block of its own, and
+ * the launches of the call are kept for pt_launch_log.  enable = 2: the same, but only the trace
+ * launches are bracketed with events (a quarter of the event records).  0: off. */
 int pt_set_profiling(pt_ctx *ctx, int enable);
+
+/* No counterpart in the reference.  The launches of the last pt_render / pt_intersect that ran with
+ * profiling on and stats != NULL, in issue order: which kernel traced which level of which wavefront
+ * batch, what it counted and how long it took — so that each traversal kernel symbol can be priced
+ * against the roofline by itself (bench.py roofline.per_launch).
+ *   out    host [cap]; n_out receives the number of launches of that call (may exceed cap: only cap
+ *          records are written) */
+typedef enum { PT_STAGE_RAYGEN = 0, PT_STAGE_TRACE_CLOSEST = 1, PT_STAGE_TRACE_ANY = 2, PT_STAGE_SHADE = 3,
+               PT_STAGE_SPLAT = 4 } pt_stage;
+typedef enum { PT_KERNEL_NONE = 0, PT_KERNEL_TRACE = 1, PT_KERNEL_TRACE_META = 2, PT_KERNEL_TRACE_TOP = 3,
+               PT_KERNEL_TRACE_PAIR = 4, PT_KERNEL_TRACE_PAIR_REFILL = 5, PT_KERNEL_TRACE_PACKET = 6 } pt_kernel_id;
+typedef struct {
+    int32_t stage;      /* pt_stage; PT_STAGE_SHADE = k_list_hits + k_shade of one level */
+    int32_t kernel;     /* pt_kernel_id of a trace launch (the fetch form of the walk), else 0 */
+    int32_t level;      /* bounce level of the launch; -1: ray generation, camera pre-test, splat */
+    int32_t batch;      /* wavefront batch of the render (0 for pt_intersect) */
+    uint64_t rays, node_visits, tri_tests;   /* trace launches: the launch's own census (all 0 if the
+                                                call had more trace launches than census blocks, 256) */
+    double ms;          /* HIP events around the launch; -1 when this profiling level does not time it */
+} pt_launch_record;
+int pt_launch_log(pt_ctx *ctx, pt_launch_record *out, int32_t cap, int32_t *n_out);
+const char *pt_kernel_name(int32_t id);      /* "k_trace_meta", ... ("" for PT_KERNEL_NONE) */
 
 /* replaces: the pixel loop of ImageFilm.write_image (film/film.py:237-256):
  * rgb[y][x] = max(0, xyz2rgb(Lxyz)/weight_sum).  film_accum device [y][x][4] → rgb device

@@ -1,7 +1,7 @@
 """ctypes mirror of include/pytracer_hip.h (struct layouts and enums only)."""
 import ctypes as C
 
-PT_ABI_VERSION = 11
+PT_ABI_VERSION = 12
 PT_INTERSECT_STATIC_MAX_RAYS = 0x40000000
 PT_MAX_LOBES = 5
 
@@ -80,6 +80,15 @@ class pt_tile(C.Structure):
 
     def n_samples(self):
         return self.rows() * (self.x1 - self.x0) * (self.s1 - self.s0)
+
+
+PT_STAGE_RAYGEN, PT_STAGE_TRACE_CLOSEST, PT_STAGE_TRACE_ANY, PT_STAGE_SHADE, PT_STAGE_SPLAT = range(5)
+STAGE_NAMES = ('raygen', 'trace_closest', 'trace_any', 'shade', 'splat')
+
+
+class pt_launch_record(C.Structure):
+    _fields_ = [('stage', C.c_int32), ('kernel', C.c_int32), ('level', C.c_int32), ('batch', C.c_int32),
+                ('rays', C.c_uint64), ('node_visits', C.c_uint64), ('tri_tests', C.c_uint64), ('ms', C.c_double)]
 
 
 class pt_stats(C.Structure):

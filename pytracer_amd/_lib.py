@@ -13,7 +13,7 @@ if os.environ.get('PYTRACER_HIP_LIB'):        # kernel A/B experiments only (scr
     LIB_PATH = os.path.abspath(os.environ['PYTRACER_HIP_LIB'])
 
 EXPORTS = ('pt_version', 'pt_ctx_create', 'pt_ctx_destroy', 'pt_last_error', 'pt_scene_upload', 'pt_intersect',
-           'pt_intersect_static', 'pt_render', 'pt_film_resolve', 'pt_film_to_u8', 'pt_set_profiling', 'pt_bvh_build', 'pt_build_last_error',
+           'pt_intersect_static', 'pt_render', 'pt_film_resolve', 'pt_film_to_u8', 'pt_set_profiling', 'pt_launch_log', 'pt_kernel_name', 'pt_bvh_build', 'pt_build_last_error',
            'pt_loop_subdiv', 'pt_subdiv_last_error')
 
 _lib = None
@@ -50,6 +50,9 @@ def lib():
                                 C.POINTER(A.pt_sampler_desc), C.POINTER(A.pt_integrator_desc), C.POINTER(A.pt_tile),
                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(A.pt_stats), C.c_void_p]
         L.pt_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.pt_launch_log.argtypes = [C.c_void_p, C.POINTER(A.pt_launch_record), C.c_int32, C.POINTER(C.c_int32)]
+        L.pt_kernel_name.restype = C.c_char_p
+        L.pt_kernel_name.argtypes = [C.c_int32]
         L.pt_film_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.pt_film_to_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.pt_bvh_build.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -91,7 +94,18 @@ class Context(object):
             raise PtError(rc, lib().pt_last_error(self._h).decode('utf-8', 'replace'))
 
     def set_profiling(self, enable):
-        self._check(lib().pt_set_profiling(self._h, int(bool(enable))))
+        """0 / False off; 1 / True: every launch timed and logged; 2: only the trace launches timed"""
+        self._check(lib().pt_set_profiling(self._h, int(enable)))
+
+    def launch_log(self):
+        """The launches of the last profiled render / intersect (pt_launch_log) as a list of dicts."""
+        n = C.c_int32(0)
+        self._check(lib().pt_launch_log(self._h, None, 0, C.byref(n)))
+        buf = (A.pt_launch_record * max(n.value, 1))()
+        self._check(lib().pt_launch_log(self._h, buf, n.value, C.byref(n)))
+        return [{'stage': A.STAGE_NAMES[r.stage], 'kernel': lib().pt_kernel_name(r.kernel).decode(), 'level': r.level,
+                 'batch': r.batch, 'rays': int(r.rays), 'node_visits': int(r.node_visits), 'tri_tests': int(r.tri_tests),
+                 'ms': float(r.ms)} for r in buf[:n.value]]
 
     def upload(self, flat):
         d = flat.desc()

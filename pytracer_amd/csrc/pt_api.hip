@@ -14,6 +14,20 @@
 
 #include "pt_kernels.h"
 
+// One launch of a profiled call (pt_launch_log): which kernel, on which level of which wavefront batch, the census
+// block it counted into and the event pair around it.
+struct LogEnt {
+    int stage, kernel, level, batch;
+    int slice;                       // census block of a trace launch, -1: none
+    long ev;                         // index of the first event of its pair, -1: not timed
+    pt_launch_record rec;            // filled by read_counters
+};
+// Census blocks: with profiling on every trace launch of a call counts into a block of its own, so that each launch
+// can be priced (rays, node visits, triangle tests, ms: bench.py roofline.per_launch); launches beyond the last
+// block share it.  256 blocks x 20 KB = 5 MB per context.
+#define PT_LOG_SLICES 256
+#define PT_SLICE_WORDS (PT_CNT_SHARDS * CNT_COUNT)
+
 struct pt_ctx {
     int device;
     char err[512];
@@ -28,6 +42,7 @@ struct pt_ctx {
     int use_packet;          // PT_TRACE_PACKET: bit 0 / bit 1 = the level-0 closest-hit / any-hit launches of a render walk per wave; unset (-1) = pt_render decides
     int packet_occ[2];
     int pair_refill;         // PT_PAIR_REFILL: k_trace_pair launches of a render refill their lanes (needs the cursors); unset (-1) = by tree size
+    int refill_min;          // PT_REFILL_MIN: lanes that must be waiting before k_trace_pair_refill claims new rays (0: the kernel's default)
     int trace_dynamic;       // PT_TRACE_DYNAMIC: 0 = static chunk assignment in the trace launches of a render, else (default) chunk cursors
     size_t brdf_bytes;
     int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
@@ -53,7 +68,8 @@ struct pt_ctx {
                              // unset = for trees beyond the L2 (>= 2^18 nodes = 16 MB).  Measured:
                              // head mesh 5.5 k nodes -5 %, head_loop 352 k nodes +5 %, 10^6-triangle soup +19 %
     int *hit_idx;            // [cap] hit list of the current closest-hit trace (HitList::idx)
-    int *d_counts;           // [5][PT_SEG]: region fill counters of q0, q1, shadow queue 0, the hit list, shadow queue 1
+    int *d_counts;           // [6][PT_CNT_BLOCK]: region counter blocks of q0, q1, shadow queue 0, the hit list of even
+                             // levels, shadow queue 1, the hit list of odd levels
     int trace_occ[2];        // resident blocks/CU of the closest / any trace kernels (0 = not queried)
     int pair_occ[2];         // the same for k_trace_pair
     int pair_levels;         // todo levels the tree needs; the first pair_lds_levels of them live in LDS (PT_PAIR_LDS_LEVELS)
@@ -61,16 +77,20 @@ struct pt_ctx {
     long pair_max_blocks;    // grid limit of k_trace_pair = what d_spill was sized for (a multiple of PT_SEG_BLOCKS)
     void *d_spill;           // global part of k_trace_pair's todo stacks
     RenderConst *d_rc;
-    unsigned long long *d_counters;
+    RenderConst *h_rc;       // what d_rc holds (valid when rc_valid): an identical descriptor set is not copied again
+    bool rc_valid;
+    unsigned long long *d_counters;   // [PT_LOG_SLICES] census blocks (one per trace launch when profiling, else block 0) + 4 words
     int n_cu;
-    // measurement (pt_set_profiling): event pairs around launches, tagged with a stage
-    bool profiling;
+    // measurement (pt_set_profiling): event pairs around launches; every launch of a profiled call is logged
+    int profiling;                   // 0 off; 1 every launch; 2 trace launches only
     std::vector<hipEvent_t> *ev;     // pool, used pairwise
-    std::vector<int> *ev_stage;      // stage of pair k
+    std::vector<LogEnt> *log;        // launches of the last profiled pt_render / pt_intersect (pt_launch_log)
     size_t ev_used;
+    int slices_used;                 // census blocks handed out in this call
 };
 
-enum { STAGE_RAYGEN = 0, STAGE_TRACE_CLOSEST, STAGE_TRACE_ANY, STAGE_SHADE, STAGE_SPLAT, STAGE_COUNT };
+enum { STAGE_RAYGEN = PT_STAGE_RAYGEN, STAGE_TRACE_CLOSEST = PT_STAGE_TRACE_CLOSEST, STAGE_TRACE_ANY = PT_STAGE_TRACE_ANY,
+       STAGE_SHADE = PT_STAGE_SHADE, STAGE_SPLAT = PT_STAGE_SPLAT, STAGE_COUNT };
 
 static int fail(pt_ctx *c, int code, const char *fmt, ...) {
     if (c) {
@@ -161,7 +181,7 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // region fill counters of q0, q1, shadow queue 0, the hit list, shadow queue 1
-    CREATE_CHK(hipMalloc((void **)&c->d_counts, 5 * PT_CNT_BLOCK * sizeof(int)));
+    CREATE_CHK(hipMalloc((void **)&c->d_counts, 6 * PT_CNT_BLOCK * sizeof(int)));
     c->use_top = -1;
     if (const char *e = getenv("PT_TRACE_TOP")) c->use_top = atoi(e);
     c->use_meta = 1;
@@ -169,8 +189,10 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     c->use_pair = -1;
     if (const char *e = getenv("PT_TRACE_PAIR")) c->use_pair = atoi(e);
     CREATE_CHK(hipMalloc((void **)&c->d_rc, sizeof(RenderConst)));
-    // + 4 words behind the census shards: the channel maxima of pt_film_to_u8
-    CREATE_CHK(hipMalloc((void **)&c->d_counters, (PT_CNT_SHARDS * CNT_COUNT + 4) * sizeof(unsigned long long)));
+    c->h_rc = (RenderConst *)calloc(1, sizeof(RenderConst));
+    if (!c->h_rc) { (void)pt_ctx_destroy(c); return PT_ERR_CAPACITY; }
+    // + 4 words behind the census blocks: the channel maxima of pt_film_to_u8
+    CREATE_CHK(hipMalloc((void **)&c->d_counters, ((size_t)PT_LOG_SLICES * PT_SLICE_WORDS + 4) * sizeof(unsigned long long)));
     c->overlap = 1;
     if (const char *e = getenv("PT_OVERLAP")) c->overlap = atoi(e);
     c->trace_dynamic = -1;
@@ -178,6 +200,7 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     c->use_packet = -1;
     if (const char *e = getenv("PT_TRACE_PACKET")) c->use_packet = atoi(e);
     if (const char *e = getenv("PT_PAIR_REFILL")) c->pair_refill = atoi(e);
+    if (const char *e = getenv("PT_REFILL_MIN")) c->refill_min = atoi(e);
     c->shade_dynamic = -1;
     if (const char *e = getenv("PT_SHADE_DYNAMIC")) c->shade_dynamic = atoi(e);
     if (const char *e = getenv("PT_TRACE_DYNAMIC")) c->trace_dynamic = atoi(e);
@@ -187,47 +210,88 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
         CREATE_CHK(hipEventCreateWithFlags(&c->ev_any[k], hipEventDisableTiming));
     }
     c->ev = new std::vector<hipEvent_t>();
-    c->ev_stage = new std::vector<int>();
+    c->log = new std::vector<LogEnt>();
     *out = c;
     return PT_OK;
 }
 
 extern "C" int pt_set_profiling(pt_ctx *c, int enable) {
     if (!c) return PT_ERR_ARG;
-    c->profiling = enable != 0;
+    c->profiling = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     return PT_OK;
 }
 
-// Brackets one launch with a pair of events on `stream` (no-op unless profiling).
+extern "C" const char *pt_kernel_name(int32_t id) {
+    switch (id) {
+    case PT_KERNEL_TRACE: return "k_trace";
+    case PT_KERNEL_TRACE_META: return "k_trace_meta";
+    case PT_KERNEL_TRACE_TOP: return "k_trace_top";
+    case PT_KERNEL_TRACE_PAIR: return "k_trace_pair";
+    case PT_KERNEL_TRACE_PAIR_REFILL: return "k_trace_pair_refill";
+    case PT_KERNEL_TRACE_PACKET: return "k_trace_packet";
+    default: return "";
+    }
+}
+
+// One logged launch of a profiled call: an entry in c->log, a pair of events on `stream` around it when this
+// profiling level times its stage, and (trace launches) a census block of its own.  No-op unless profiling.
 struct StageTimer {
     pt_ctx *c;
     hipStream_t stream;
-    bool on;
-    StageTimer(pt_ctx *c_, hipStream_t s, int stage) : c(c_), stream(s), on(c_->profiling) {
-        if (!on) return;
+    bool timed;
+    long idx;                        // entry in c->log, -1: nothing logged
+    StageTimer(pt_ctx *c_, hipStream_t s, int stage, int level = -1, int batch = 0) : c(c_), stream(s), timed(false), idx(-1) {
+        if (!c->profiling) return;
+        const bool trace = stage == STAGE_TRACE_CLOSEST || stage == STAGE_TRACE_ANY;
+        LogEnt e;
+        memset(&e, 0, sizeof(e));
+        e.stage = stage; e.level = level; e.batch = batch; e.slice = -1; e.ev = -1;
+        if (trace) {
+            e.slice = c->slices_used < PT_LOG_SLICES ? c->slices_used : PT_LOG_SLICES - 1;
+            c->slices_used++;
+        }
+        c->log->push_back(e);
+        idx = (long)c->log->size() - 1;
+        if (c->profiling == 2 && !trace) return;
         if (c->ev_used + 2 > c->ev->size()) {
             hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
             c->ev->push_back(a);
             c->ev->push_back(b);
         }
-        if (c->ev_stage->size() < c->ev_used / 2 + 1) c->ev_stage->push_back(stage);
-        else (*c->ev_stage)[c->ev_used / 2] = stage;
+        (*c->log)[(size_t)idx].ev = (long)c->ev_used;
+        timed = true;
         (void)hipEventRecord((*c->ev)[c->ev_used], stream);
     }
+    // the census block this launch counts into (`all` = the call's block 0 when nothing is logged)
+    unsigned long long *counters(unsigned long long *all) const {
+        const int slice = idx >= 0 ? (*c->log)[(size_t)idx].slice : -1;
+        return (all && slice >= 0) ? c->d_counters + (size_t)slice * PT_SLICE_WORDS : all;
+    }
+    void set_kernel(int id) { if (idx >= 0) (*c->log)[(size_t)idx].kernel = id; }
     ~StageTimer() {
-        if (!on) return;
+        if (!timed) return;
         (void)hipEventRecord((*c->ev)[c->ev_used + 1], stream);
         c->ev_used += 2;
     }
 };
 
+// a profiled call starts an empty log
+static void log_begin(pt_ctx *c) {
+    c->ev_used = 0;
+    c->slices_used = 0;
+    c->log->clear();
+}
+
 static void collect_timing(pt_ctx *c, pt_stats *stats) {
-    // caller has synchronised the stream
-    for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
+    // caller has synchronised the stream(s)
+    for (LogEnt &e : *c->log) {
+        e.rec.stage = e.stage; e.rec.kernel = e.kernel; e.rec.level = e.level; e.rec.batch = e.batch;
+        e.rec.ms = -1.;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, (*c->ev)[k], (*c->ev)[k + 1]) != hipSuccess) continue;
-        switch ((*c->ev_stage)[k / 2]) {
+        if (e.ev < 0 || hipEventElapsedTime(&ms, (*c->ev)[(size_t)e.ev], (*c->ev)[(size_t)e.ev + 1]) != hipSuccess) continue;
+        e.rec.ms = ms;
+        switch (e.stage) {
         case STAGE_RAYGEN: stats->ms_raygen += ms; break;
         case STAGE_TRACE_CLOSEST: stats->ms_trace_closest += ms; stats->launches_trace_closest++; break;
         case STAGE_TRACE_ANY: stats->ms_trace_any += ms; stats->launches_trace_any++; break;
@@ -236,6 +300,14 @@ static void collect_timing(pt_ctx *c, pt_stats *stats) {
         }
     }
     c->ev_used = 0;
+}
+
+extern "C" int pt_launch_log(pt_ctx *c, pt_launch_record *out, int32_t cap, int32_t *n_out) {
+    if (!c || !n_out || cap < 0 || (cap > 0 && !out)) return PT_ERR_ARG;
+    const size_t n = c->log->size();
+    *n_out = (int32_t)n;
+    for (size_t k = 0; k < n && k < (size_t)cap; k++) out[k] = (*c->log)[k].rec;
+    return PT_OK;
 }
 
 static void free_scene(pt_ctx *c) {
@@ -255,6 +327,7 @@ extern "C" int pt_ctx_destroy(pt_ctx *c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_rc) (void)hipFree(c->d_rc);
+    free(c->h_rc);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
     for (int k = 0; k < 2; k++) {
@@ -262,7 +335,7 @@ extern "C" int pt_ctx_destroy(pt_ctx *c) {
         if (c->ev_any[k]) (void)hipEventDestroy(c->ev_any[k]);
     }
     if (c->ev) { for (hipEvent_t e : *c->ev) (void)hipEventDestroy(e); delete c->ev; }
-    delete c->ev_stage;
+    delete c->log;
     free(c);
     return PT_OK;
 }
@@ -713,7 +786,9 @@ static int trace_grid(pt_ctx *c, long n, bool any) {
 // every trace launch goes through here: top-of-tree kernel when the tree qualified at upload
 static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t stream, const double *rays, long stride,
                                const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t, double *out_b1,
-                               double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
+                               double *out_b2, const ShadowResolve &rs, unsigned long long *counters, int *kid = nullptr) {
+    int kid_dummy;
+    if (!kid) kid = &kid_dummy;
     // children-pair walk (PT_TRACE_PAIR: bit 0 = closest-hit launches, bit 1 = any-hit launches; unset: by tree size)
     // Measured (profiles/r02_*): head mesh (5.5 k nodes, tree L1/L2-resident, k_trace_meta
     // applies) closest 40.7 -> 45.7 ms, any 20.5 -> 20.5 ms: off; head_loop (352 k nodes) closest 2.1 -> 1.4 ms, any
@@ -724,6 +799,7 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
         if (occ == 0) occ = pt_trace_packet_occupancy(any, c->stack_need);
         const long blocks = (n_bound + PT_BLOCK - 1) / PT_BLOCK;
         const int grid = (int)std::max<long>(1, std::min<long>(blocks, (long)c->n_cu * occ));
+        *kid = PT_KERNEL_TRACE_PACKET;
         return pt_launch_trace_packet(any, c->stack_need, grid, stream, c->sc, rays, stride, seg_counts, seg, out_prim, out_t,
                                       out_b1, out_b2, rs, counters);
     }
@@ -747,26 +823,32 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
         // lane refill (k_trace_pair_refill) pays where walks are long and uneven: by tree size unless PT_PAIR_REFILL says
         const bool refill = c->pair_refill < 0 ? c->sc.n_nodes >= (1 << 20) : c->pair_refill != 0;
         char *spill = (char *)c->d_spill + (any ? pt_trace_pair_spill_bytes(c->pair_levels, c->pair_max_blocks * 256) : 0);
+        *kid = (seg_counts && refill && (n_val & PT_TRACE_DYNAMIC)) ? PT_KERNEL_TRACE_PAIR_REFILL : PT_KERNEL_TRACE_PAIR;
         return pt_launch_trace_pair(any, c->pair_lds_levels, spill, (int)grid, stream, c->sc, rays, stride, seg_counts,
-                                    seg, (seg_counts && refill) ? (n_val | PT_TRACE_REFILL) : n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+                                    seg, (seg_counts && refill) ? (n_val | PT_TRACE_REFILL) : n_val, out_prim, out_t, out_b1, out_b2, rs, counters,
+                                    c->refill_min);
     }
     if (c->meta_stack > 0 && c->use_top <= 0 && (c->use_meta > 1 || (c->use_meta == 1 && !any))) {
         const long blocks = (n_bound + 1023) / 1024;
         const int grid = (int)std::max<long>(1, std::min<long>(blocks, c->n_cu));
+        *kid = PT_KERNEL_TRACE_META;
         return pt_launch_trace_meta(any, c->meta_stack, grid, stream, c->sc, rays, stride, seg_counts, seg, n_val, out_prim,
                                     out_t, out_b1, out_b2, rs, counters);
     }
     if (c->top_stack > 0 && (c->use_top > 0 || (c->use_top < 0 && c->sc.n_nodes >= (1 << 18)))) {
         const long blocks = (n_bound + 1023) / 1024;
         const int grid = (int)std::max<long>(1, std::min<long>(blocks, c->n_cu));
+        *kid = PT_KERNEL_TRACE_TOP;
         return pt_launch_trace_top(any, c->top_stack, grid, stream, c->sc, rays, stride, seg_counts, seg, n_val, out_prim,
                                    out_t, out_b1, out_b2, rs, counters);
     }
+    *kid = PT_KERNEL_TRACE;
     return pt_launch_trace(any, c->stack_need, trace_grid(c, n_bound, any), stream, c->sc, rays, stride, seg_counts, seg,
                            n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
 }
 
 // Sums the census shards at `src` (device) into stats.  Host side on the stack: no allocation of any kind.
+static void add_census(const unsigned long long *h, pt_stats *stats);
 static int read_counters_from(pt_ctx *c, const unsigned long long *src, hipStream_t stream, pt_stats *stats) {
     static_assert(CNT_COUNT <= 16, "counter block");
     unsigned long long sh[PT_CNT_SHARDS * CNT_COUNT];
@@ -775,6 +857,10 @@ static int read_counters_from(pt_ctx *c, const unsigned long long *src, hipStrea
     unsigned long long h[CNT_COUNT] = {0};
     for (int k = 0; k < PT_CNT_SHARDS; k++)
         for (int j = 0; j < CNT_COUNT; j++) h[j] += sh[(size_t)k * CNT_COUNT + j];
+    add_census(h, stats);
+    return PT_OK;
+}
+static void add_census(const unsigned long long *h, pt_stats *stats) {
     stats->node_visits += h[CNT_NODE_VISITS];
     stats->tri_tests += h[CNT_TRI_TESTS];
     stats->rays_closest += h[CNT_RAYS_CLOSEST];
@@ -785,13 +871,33 @@ static int read_counters_from(pt_ctx *c, const unsigned long long *src, hipStrea
     stats->guard_inf += h[CNT_GUARD_INF];
     stats->node_visits_any += h[CNT_NODE_VISITS_ANY];
     stats->tri_tests_any += h[CNT_TRI_TESTS_ANY];
-    return PT_OK;
 }
 
+// The census of a call: block 0 alone, or (profiling) every block a trace launch of this call counted into, each
+// also written to that launch's log record.  The caller's stream is synchronised.
 static int read_counters(pt_ctx *c, hipStream_t stream, pt_stats *stats) {
-    int rc = read_counters_from(c, c->d_counters, stream, stats);
-    if (rc == PT_OK && c->profiling) collect_timing(c, stats);
-    return rc;
+    if (!c->profiling) return read_counters_from(c, c->d_counters, stream, stats);
+    const int ns = std::max(1, std::min(c->slices_used, PT_LOG_SLICES));
+    std::vector<unsigned long long> host((size_t)ns * PT_SLICE_WORDS);
+    HIPCHK(c, hipMemcpyAsync(host.data(), c->d_counters, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(c, hipStreamSynchronize(stream));
+    std::vector<unsigned long long> sums((size_t)ns * CNT_COUNT, 0ull);
+    for (int s_ = 0; s_ < ns; s_++) {
+        unsigned long long *h = sums.data() + (size_t)s_ * CNT_COUNT;
+        for (int k = 0; k < PT_CNT_SHARDS; k++)
+            for (int j = 0; j < CNT_COUNT; j++) h[j] += host[((size_t)s_ * PT_CNT_SHARDS + k) * CNT_COUNT + j];
+        add_census(h, stats);
+    }
+    collect_timing(c, stats);
+    for (LogEnt &e : *c->log) {
+        if (e.slice < 0 || e.slice >= ns) continue;
+        const bool shared = e.slice == PT_LOG_SLICES - 1 && c->slices_used > PT_LOG_SLICES;   // more launches than blocks
+        const unsigned long long *h = sums.data() + (size_t)e.slice * CNT_COUNT;
+        e.rec.rays = shared ? 0 : h[CNT_RAYS_CLOSEST] + h[CNT_RAYS_ANY];
+        e.rec.node_visits = shared ? 0 : h[CNT_NODE_VISITS];
+        e.rec.tri_tests = shared ? 0 : h[CNT_TRI_TESTS];
+    }
+    return PT_OK;
 }
 
 extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hit, int32_t *prim, double *t,
@@ -806,15 +912,17 @@ extern "C" int pt_intersect(pt_ctx *c, const double *rays, int64_t n, int any_hi
     HIPCHK(c, dg.err);
     unsigned long long *cnt = nullptr;
     if (stats) {
-        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, PT_CNT_SHARDS * CNT_COUNT * sizeof(unsigned long long), stream));
+        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, PT_SLICE_WORDS * sizeof(unsigned long long), stream));
         cnt = c->d_counters;
     }
     ShadowResolve rs = {nullptr, 0, nullptr, nullptr, 0};
-    c->ev_used = 0;
+    log_begin(c);
     {
         StageTimer tm(c, stream, any_hit ? STAGE_TRACE_ANY : STAGE_TRACE_CLOSEST);
+        int kid = 0;
         HIPCHK(c, launch_trace(c, any_hit != 0, (long)n, stream, rays, (long)n, nullptr, 0, (int)n, prim, t, b1, b2, rs,
-                               cnt));
+                               tm.counters(cnt), &kid));
+        tm.set_kernel(kid);
     }
     if (stats) return read_counters(c, stream, stats);
     return PT_OK;
@@ -1001,10 +1109,19 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             HIPCHK(c, hipStreamWaitEvent(stream, c->ev_any[k], 0));
             c->any_pending[k] = false;
         }
-    HIPCHK(c, hipMemcpyAsync(c->d_rc, &h, sizeof(h), hipMemcpyHostToDevice, stream));
+    // the descriptor block stays resident: a call with the descriptors of the previous one (every step of a
+    // progressive or benchmark loop) copies nothing
+    if (!c->rc_valid || memcmp(c->h_rc, &h, sizeof(h)) != 0) {
+        c->rc_valid = false;
+        HIPCHK(c, hipMemcpyAsync(c->d_rc, &h, sizeof(h), hipMemcpyHostToDevice, stream));
+        memcpy(c->h_rc, &h, sizeof(h));
+        c->rc_valid = true;
+    }
     unsigned long long *cnt = nullptr;
     if (stats) {
-        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, PT_CNT_SHARDS * CNT_COUNT * sizeof(unsigned long long), stream));
+        // profiling: one census block per trace launch (read_counters), all cleared here
+        const size_t blocks = c->profiling ? PT_LOG_SLICES : 1;
+        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, blocks * PT_SLICE_WORDS * sizeof(unsigned long long), stream));
         cnt = c->d_counters;
     }
     // number of shade levels: Path shades bounce 0..max_depth; Direct recurses only through
@@ -1027,33 +1144,41 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     // (~25 us against ~10 us for 64 per-lane walks side by side), which a 16 k-ray launch cannot hide (C1: 0.49 vs 0.54 ms)
     if (use_packet < 0)
         use_packet = std::min(batch, total) >= (1l << 20) ? (1 | ((ig->kind == PT_INTEG_PATH && c->meta_stack > 0) ? 2 : 0)) : 0;
+    // Counter blocks of the hit lists alternate with the level: k_list_hits(k) fills block k & 1 and resets the other
+    // one for level k + 1 (nothing has touched it since k_shade(k - 1) ended); k_raygen resets block 0.
+    auto hit_count = [&](int level) { return c->d_counts + ((level & 1) ? 5 : 3) * PT_CNT_BLOCK; };
     auto hit_list = [&](int level) {
         HitList hl{};
-        hl.idx = c->hit_idx; hl.count = c->d_counts + 3 * PT_CNT_BLOCK;
+        hl.idx = c->hit_idx; hl.count = hit_count(level);
         hl.esc = c->st.esc;
         hl.add_escape = level > 0;
         hl.dynamic = shade_dyn;
         hl.tri_cls = (const unsigned char *)c->d_tri_cls;
         return hl;
     };
-    c->ev_used = 0;
+    log_begin(c);
+    int batch_no = -1;
     for (long base = 0; base < total; base += batch) {
+        batch_no++;
         const int nb = (int)std::min(batch, total - base);
         const int g = (nb + PT_BLOCK - 1) / PT_BLOCK;
         const int gs = (int)std::max<long>(1, std::min<long>((nb + PT_BLOCK - 1) / PT_BLOCK, (long)c->n_cu * 4));
         {
-            StageTimer tm(c, stream, STAGE_RAYGEN);
-            HIPCHK(c, pt_launch_raygen(g, stream, c->d_rc, base, nb, gshift, c->q[0], c->st, cnt));
+            StageTimer tm(c, stream, STAGE_RAYGEN, -1, batch_no);
+            HIPCHK(c, pt_launch_raygen(g, stream, c->d_rc, base, nb, gshift, c->q[0], c->st, cnt, hit_count(0)));
         }
+        int kid = 0;
         if (ig->pretest) {   // renderer.py:168: same hit flag as the closest-hit pass below
-            StageTimer tm(c, stream, STAGE_TRACE_ANY);
+            StageTimer tm(c, stream, STAGE_TRACE_ANY, -1, batch_no);
             HIPCHK(c, launch_trace(c, true, nb, stream, c->q[0].rays, c->q[0].stride, c->q[0].count, c->q[0].seg, 0,
-                                   nullptr, nullptr, nullptr, nullptr, no_rs, cnt));
+                                   nullptr, nullptr, nullptr, nullptr, no_rs, tm.counters(cnt), &kid));
+            tm.set_kernel(kid);
         }
         {
-            StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
+            StageTimer tm(c, stream, STAGE_TRACE_CLOSEST, 0, batch_no);
             HIPCHK(c, launch_trace(c, false, nb, stream, c->q[0].rays, c->q[0].stride, c->q[0].count, c->q[0].seg,
-                                   dyn | ((dyn && (use_packet & 1)) ? PT_TRACE_PACKET : 0), c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, cnt));
+                                   dyn | ((dyn && (use_packet & 1)) ? PT_TRACE_PACKET : 0), c->q[0].prim, c->q[0].t, c->q[0].b1, c->q[0].b2, no_rs, tm.counters(cnt), &kid));
+            tm.set_kernel(kid);
         }
         int cur = 0;
         // The any-hit (shadow) trace of level k depends only on shade(k); level k+1's closest-hit trace, hit list and
@@ -1072,12 +1197,12 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
                 HIPCHK(c, hipStreamWaitEvent(stream, c->ev_any[sb], 0));
                 any_pending[sb] = false;
             }
-            HIPCHK(c, hipMemsetAsync(qout.count, 0, PT_CNT_BLOCK * sizeof(int), stream));
-            HIPCHK(c, hipMemsetAsync(sh.count, 0, PT_CNT_BLOCK * sizeof(int), stream));
             {
-                StageTimer tm(c, stream, STAGE_SHADE);
-                HIPCHK(c, hipMemsetAsync(c->d_counts + 3 * PT_CNT_BLOCK, 0, PT_CNT_BLOCK * sizeof(int), stream));
-                HIPCHK(c, pt_launch_list_hits(gs * 2, stream, qin, hit_list(level)));
+                StageTimer tm(c, stream, STAGE_SHADE, level, batch_no);
+                // k_list_hits also resets the counter blocks that k_shade and the next level fill: the continuation
+                // queue, this level's shadow queue (its last reader, the any-hit trace of level - 2 or level - 1, is
+                // done: the wait above / stream order) and the next level's hit list
+                HIPCHK(c, pt_launch_list_hits(gs * 2, stream, qin, hit_list(level), qout.count, sh.count, hit_count(level + 1)));
                 HIPCHK(c, pt_launch_shade(ig->kind, ig->shade_f32 != 0, gs, stream, c->sc, c->d_rc, base, level, qin,
                                           hit_list(level), qout, sh, c->st));
             }
@@ -1089,29 +1214,31 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
                 any_stream = c->aux;
             }
             {
-                StageTimer tm(c, any_stream, STAGE_TRACE_ANY);
+                StageTimer tm(c, any_stream, STAGE_TRACE_ANY, level, batch_no);
                 HIPCHK(c, launch_trace(c, true, (long)nb * spv, any_stream, sh.rays, sh.stride, sh.count, sh.seg,
                                        dyn | ((dyn && level == 0 && (use_packet & 2)) ? PT_TRACE_PACKET : 0), nullptr, nullptr,
-                                       nullptr, nullptr, rs, cnt));
+                                       nullptr, nullptr, rs, tm.counters(cnt), &kid));
+                tm.set_kernel(kid);
             }
             if (ovl) {
                 HIPCHK(c, hipEventRecord(c->ev_any[sb], c->aux));
                 any_pending[sb] = true;
             }
             if (getenv("PT_DEBUG_LEVELS") && base == 0) {   // debugging aid: queue sizes per level (syncs)
-                std::vector<int> h(5 * PT_CNT_BLOCK);
-                long tot[5] = {0, 0, 0, 0, 0};
+                std::vector<int> h(6 * PT_CNT_BLOCK);
+                long tot[6] = {0, 0, 0, 0, 0, 0};
                 (void)hipStreamSynchronize(c->aux);
                 (void)hipMemcpyAsync(h.data(), c->d_counts, h.size() * sizeof(int), hipMemcpyDeviceToHost, stream);
                 (void)hipStreamSynchronize(stream);
-                for (int k = 0; k < 5 * PT_CNT_BLOCK; k += PT_CNT_STRIDE) tot[k / PT_CNT_BLOCK] += h[k];
-                fprintf(stderr, "[pt] level %d: in %ld (hits %ld), continuation %ld, shadow %ld\n", level, tot[cur], tot[3],
+                for (int k = 0; k < 6 * PT_CNT_BLOCK; k += PT_CNT_STRIDE) tot[k / PT_CNT_BLOCK] += h[k];
+                fprintf(stderr, "[pt] level %d: in %ld (hits %ld), continuation %ld, shadow %ld\n", level, tot[cur], tot[(level & 1) ? 5 : 3],
                         tot[cur ^ 1], tot[sb ? 4 : 2]);
             }
             if (level + 1 < levels) {
-                StageTimer tm(c, stream, STAGE_TRACE_CLOSEST);
+                StageTimer tm(c, stream, STAGE_TRACE_CLOSEST, level + 1, batch_no);
                 HIPCHK(c, launch_trace(c, false, nb, stream, qout.rays, qout.stride, qout.count, qout.seg, dyn, qout.prim,
-                                       qout.t, qout.b1, qout.b2, no_rs, cnt));
+                                       qout.t, qout.b1, qout.b2, no_rs, tm.counters(cnt), &kid));
+                tm.set_kernel(kid);
                 cur ^= 1;
             }
         }
@@ -1121,7 +1248,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
                 any_pending[k] = false;
             }
         {
-            StageTimer tm(c, stream, STAGE_SPLAT);
+            StageTimer tm(c, stream, STAGE_SPLAT, -1, batch_no);
             HIPCHK(c, pt_launch_splat(stream, c->d_rc, *tile, *film, base, nb, c->st, film_accum, sample_L, cnt));
         }
     }
@@ -1147,6 +1274,6 @@ extern "C" int pt_film_to_u8(pt_ctx *c, const double *rgb, int32_t x_cnt, int32_
     DeviceGuard dg(c->device);
     HIPCHK(c, dg.err);
     HIPCHK(c, pt_launch_film_to_u8((hipStream_t)stream_, rgb, (long)x_cnt * y_cnt,
-                                   c->d_counters + PT_CNT_SHARDS * CNT_COUNT, out));
+                                   c->d_counters + (size_t)PT_LOG_SLICES * PT_SLICE_WORDS, out));
     return PT_OK;
 }

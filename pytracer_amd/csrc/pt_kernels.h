@@ -168,10 +168,12 @@ int pt_trace_pair_occupancy(bool any, int lds_levels);
 hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid, hipStream_t stream, const DScene &sc,
                                 const double *rays, long stride, const int *seg_counts, long seg, int n_val, int *out_prim,
                                 double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
-                                unsigned long long *counters);
+                                unsigned long long *counters, int refill_min);
 hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, int gshift,
-                            const Queue &q, const PathState &st, unsigned long long *counters);
-hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, const HitList &hl);
+                            const Queue &q, const PathState &st, unsigned long long *counters, int *clr_hits);
+// clr0..2 (nullable): counter blocks (PT_CNT_BLOCK ints each) the kernel resets for the launches after it
+hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, const HitList &hl, int *clr0, int *clr1,
+                               int *clr2);
 hipError_t pt_launch_shade(int kind, bool f32, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc,
                            long base, int level, const Queue &qin, const HitList &hl, const Queue &qout,
                            const ShadowQueue &sh, const PathState &st);

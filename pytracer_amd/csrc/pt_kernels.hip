@@ -812,7 +812,7 @@ int pt_trace_pair_occupancy(bool any, int lds_levels) {
 hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid, hipStream_t stream, const DScene &sc,
                                 const double *rays, long stride, const int *seg_counts, long seg, int n_val, int *out_prim,
                                 double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
-                                unsigned long long *counters) {
+                                unsigned long long *counters, int refill_min) {
     static bool attr_set[PT_MAX_DEVICES][2];
     const size_t lds = pt_trace_pair_lds(lds_levels);
     int dev = 0;
@@ -829,8 +829,7 @@ hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid,
     }
     // lane refill needs the region cursors: segmented input of a launch with PT_TRACE_DYNAMIC
     const bool refill = seg_counts && (n_val & PT_TRACE_DYNAMIC) && (n_val & PT_TRACE_REFILL);
-    static int refill_min = 0;
-    if (!refill_min) { const char *e = getenv("PT_REFILL_MIN"); refill_min = e && atoi(e) > 0 ? atoi(e) : PT_REFILL_MIN; }
+    if (refill_min < 1 || refill_min > 64) refill_min = PT_REFILL_MIN;
     if (refill) {
         if (any)
             hipLaunchKernelGGL((k_trace_pair_refill<true>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride,
@@ -1066,6 +1065,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_PACKET_WAVES) void k_trace_packet(DSce
                     const int c1 = node + 1, c2 = meta.x;
                     PacketEnt p;
                     p.pad = 0;
+#ifdef PT_DEBUG_ASSERT
+                    assert(sp + 3 <= cap);      // <= 3 entries per interior level of the current path (see `cap` below)
+#endif
                     // far children under near children; the two groups share no lane, so their order is free.  The
                     // topmost entry stays in registers.
                     if (posm) { p.node = c2; p.lo = (unsigned)posm; p.hi = (unsigned)(posm >> 32); stk[sp++] = p; }
@@ -1100,6 +1102,10 @@ hipError_t pt_launch_trace_packet(bool any, int stack, int grid, hipStream_t str
                                   double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
     if (!seg_counts) return hipErrorInvalidValue;
     grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;
+    // `stack` = pt_ctx::stack_need = the deepest leaf's depth as check_tree measured it on the uploaded tree (<= 64,
+    // pt_scene_upload refuses deeper ones): a path holds at most that many interior nodes, each leaves at most three
+    // entries on the stack (header comment), so 3 x stack + 8 entries cannot overflow.  -DPT_DEBUG_ASSERT checks it.
+    if (stack < 1 || stack > 64) return hipErrorInvalidValue;
     const int cap = 3 * stack + 8;
     if (any)
         hipLaunchKernelGGL((k_trace_packet<true>), dim3(grid), dim3(PT_BLOCK), pt_trace_packet_lds(stack), stream, sc, rays,
@@ -1213,6 +1219,13 @@ __device__ inline void concentric_sample_disk(double u1, double u2, double &ox, 
     ox = r * cos(theta); oy = r * sin(theta);
 }
 
+// Region r's line of a counter block back to "empty": fill count, chunk cursor, back count (pt_kernels.h).
+__device__ __forceinline__ void pt_clear_region_line(int *__restrict__ block, int r) {
+    block[r * PT_CNT_STRIDE] = 0;
+    block[r * PT_CNT_STRIDE + PT_CNT_CURSOR] = 0;
+    block[r * PT_CNT_STRIDE + PT_CNT_BACK] = 0;
+}
+
 // Where camera sample i of a batch goes in the segmented queue (pt_kernels.h): samples travel in
 // groups of G = 2^gshift 64-sample chunks (consecutive pixels: the waves that serve a region work
 // on neighbouring pixels at any one time: +6 % on the whole render over a chunk-interleaved mapping);
@@ -1226,7 +1239,8 @@ __device__ __forceinline__ long seg_entry(int i, int gshift, long seg) {
 }
 
 __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restrict__ rcp, long base, int nb, int gshift,
-                                                     Queue q, PathState st, unsigned long long *counters) {
+                                                     Queue q, PathState st, unsigned long long *counters,
+                                                     int *__restrict__ clr_hits) {
     const RenderConst &rc = *rcp;
     const int i = blockIdx.x * PT_BLOCK + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < PT_SEG) {
@@ -1239,6 +1253,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
         if (r == (gl + 17 * jl) % PT_SEG) cnt -= ngroups * gsz - nb;
         q.count[r * PT_CNT_STRIDE] = cnt;
         q.count[r * PT_CNT_STRIDE + PT_CNT_CURSOR] = 0;      // the chunk cursor of a dynamic trace launch (pt_kernels.h)
+        // the hit list of level 0 (count, cursor, back count): nothing reads that block between the last k_shade
+        // that used it and this batch's first k_list_hits, so no memset node is needed for it (pt_api.hip)
+        if (clr_hits) pt_clear_region_line(clr_hits, r);
     }
     if (i >= nb) return;
     int px, py, si;
@@ -1588,8 +1605,8 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
 }
 
 hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, int gshift,
-                            const Queue &q, const PathState &st, unsigned long long *counters) {
-    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(PT_BLOCK), 0, stream, rc, base, nb, gshift, q, st, counters);
+                            const Queue &q, const PathState &st, unsigned long long *counters, int *clr_hits) {
+    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(PT_BLOCK), 0, stream, rc, base, nb, gshift, q, st, counters, clr_hits);
     return hipGetLastError();
 }
 
@@ -1603,7 +1620,16 @@ hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc,
 // atomic (with return: the dependent step of the loop) reserves the list positions of all of them — at one chunk per
 // step the waves sat parked on that round trip 91 % of their cycles (profiles/r02_head_sq.csv: 0.58 ms per launch).
 #define PT_LIST_UNROLL 4
-__global__ __launch_bounds__(PT_BLOCK) void k_list_hits(Queue q, HitList hl) {
+// It also resets the three counter blocks the launches AFTER it fill (clr0..2: this level's continuation queue and
+// shadow queue, the next level's hit list): nothing reads or writes them while this kernel runs (pt_api.hip orders the
+// streams so), and the three 8 KB memset nodes per level they replace were a tenth of the stream operations of a render.
+__global__ __launch_bounds__(PT_BLOCK) void k_list_hits(Queue q, HitList hl, int *__restrict__ clr0, int *__restrict__ clr1,
+                                                        int *__restrict__ clr2) {
+    if (blockIdx.x == 0 && threadIdx.x < PT_SEG) {
+        if (clr0) pt_clear_region_line(clr0, threadIdx.x);
+        if (clr1) pt_clear_region_line(clr1, threadIdx.x);
+        if (clr2) pt_clear_region_line(clr2, threadIdx.x);
+    }
     const int wave = (int)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6);
     const int nsub = (int)((gridDim.x * (PT_BLOCK / 64)) / PT_SEG);
     const int region = wave % PT_SEG, sub = wave / PT_SEG;
@@ -1654,9 +1680,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_list_hits(Queue q, HitList hl) {
     }
 }
 
-hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, const HitList &hl) {
+hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, const HitList &hl, int *clr0, int *clr1,
+                               int *clr2) {
     grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
-    hipLaunchKernelGGL(k_list_hits, dim3(grid), dim3(PT_BLOCK), 0, stream, q, hl);
+    hipLaunchKernelGGL(k_list_hits, dim3(grid), dim3(PT_BLOCK), 0, stream, q, hl, clr0, clr1, clr2);
     return hipGetLastError();
 }
 

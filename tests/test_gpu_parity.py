@@ -138,12 +138,20 @@ def test_axis_parallel_rays_on_box_planes(torch_cuda, ctx, golden_dir):
 
 
 @pytest.mark.parametrize('knob', ['PT_TRACE_TOP=1', 'PT_TRACE_META=2', 'PT_TRACE_META=0', 'PT_TRACE_PAIR=3',
-                                  'PT_TRACE_DYNAMIC=1', 'PT_TRACE_DYNAMIC=0', 'PT_TRACE_META=2,PT_TRACE_DYNAMIC=0'])
+                                  'PT_TRACE_DYNAMIC=1', 'PT_TRACE_DYNAMIC=0', 'PT_TRACE_META=2,PT_TRACE_DYNAMIC=0',
+                                  'PT_TRACE_PACKET=3', 'PT_TRACE_PACKET=3,PT_OVERLAP=0',
+                                  'PT_TRACE_PAIR=3,PT_PAIR_REFILL=1,PT_REFILL_MIN=5',
+                                  'PT_TRACE_PAIR=3,PT_PAIR_REFILL=1,PT_REFILL_MIN=5,PT_OVERLAP=1,PT_TRACE_PACKET=0',
+                                  'PT_TRACE_PAIR=3,PT_PAIR_REFILL=1,PT_TRACE_PACKET=3,PT_OVERLAP=1'])
 def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head, knob):
     """k_trace_top (first breadth-first nodes staged in LDS; default only for trees beyond the L2), k_trace_meta
     (child/primitive words of all nodes in LDS; default for closest-hit launches on small trees), k_trace_pair (the
     walk fetched by parent: both child boxes in one 128-byte record, the far child's verdict finished at its pop)
-    and the plain k_trace walk the same nodes in the same order: outputs and visit counts equal the oracle's."""
+    and the plain k_trace walk the same nodes in the same order: outputs and visit counts equal the oracle's.
+    The forms that only render launches can take — k_trace_packet (one walk per wave, the level-0 launches of the
+    headline render), k_trace_pair_refill (lane refill, the 10^6-triangle soup's default) and the two-stream
+    schedule — are forced on by their knobs and held to the REFERENCE's per-sample radiance and the oracle's census
+    in the whole-render leg, on three fixture scenes (head, c4mini: three light kinds, specmini: specular chains)."""
     import oracle_lib as O
     from pytracer_amd._lib import Context
     kv = dict(x.split('=') for x in knob.split(','))
@@ -169,12 +177,22 @@ def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head
                 if not any_hit:
                     assert np.array_equal(gt, ot) and np.array_equal(gb1, ob1) and np.array_equal(gb2, ob2)
                 assert sg.as_dict() == so.as_dict()
-        # and through a whole render
-        d = load(golden_dir, 'head_path_32x32x4.npz')
-        c.upload(head[1])
-        acc, L, _ = gpu_render(torch_cuda, c, d, d['sub'], d['spp'], pa.integrator_desc(A.PT_INTEG_PATH, 5, True),
-                               table=d['samples'])
-        assert rel_err(L, d['L']) < REF_RTOL
+        # and through whole renders: the reference's own per-sample radiance, the oracle's radiance and census
+        for name in ('head_path_32x32x4.npz', 'c4mini_path_24x24x4.npz', 'specmini_path_24x24x4.npz'):
+            d = load(golden_dir, name)
+            flat, osc = (head[1], head[2]) if name.startswith('head') else (pa.flat_scene_from_npz(d), None)
+            if osc is None:
+                osc = O.OracleScene(flat)
+            c.upload(flat)
+            integ = pa.integrator_desc(A.PT_INTEG_PATH, 5, True)
+            sg, so = A.pt_stats(), A.pt_stats()
+            acc, L, (cam, film, smp, tile) = gpu_render(torch_cuda, c, d, d['sub'], d['spp'], integ, table=d['samples'],
+                                                        stats=sg)
+            assert rel_err(L, d['L']) < REF_RTOL, (knob, name)
+            np.testing.assert_allclose(acc[..., 0:3], d['film_Lxyz'], rtol=REF_RTOL, atol=1e-9)
+            oacc, oL = osc.render(cam, film, smp, integ, tile, table=d['samples'], stats=so)
+            assert rel_err(L, oL) < ORACLE_RTOL, (knob, name)
+            assert_stats_close(sg, so)
     finally:
         c.close()
 

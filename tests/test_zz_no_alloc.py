@@ -73,3 +73,43 @@ def test_static_entry_matches_pt_intersect(golden_dir):
     assert rc == A.PT_ERR_CAPACITY
     assert b'maximum' in lib().pt_last_error(ctx._h)
     ctx.close()
+
+
+def test_static_calls_of_two_contexts_may_overlap(golden_dir):
+    """The overlap rule of include/pytracer_hip.h: calls on ONE context are serialised by the caller (its traversal
+    stacks are per context), calls on DIFFERENT contexts of one GPU may be in flight together and only race on the
+    census.  Two contexts forced onto the children-pair walk (PT_TRACE_PAIR=3: todo stacks partly in each context's
+    own spill area), each with its own stream, large batches issued back to back without synchronising: every hit
+    record equals the serial pt_intersect result bit for bit."""
+    import torch
+    from pytracer_amd._lib import Context
+    d = dict(np.load(os.path.join(golden_dir, 'head_mesh_scene.npz')))
+    flat = pa.flat_scene_from_npz(d)
+    os.environ.update({'PT_TRACE_PAIR': '3', 'PT_PAIR_LDS_LEVELS': '2'})     # almost every todo level in the spill area
+    ctxs = []
+    try:
+        for _ in range(2):
+            c = Context(0)
+            c.upload(flat)
+            ctxs.append(c)
+        n = 400000
+        rays = [torch.from_numpy(camera_like_rays(n, 10 + k)).cuda() for k in range(2)]
+        ref = [ctxs[k].intersect(rays[k]) for k in range(2)]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        outs = [(torch.full((n,), -7, dtype=torch.int32, device='cuda'),) +
+                tuple(torch.full((n,), -7., dtype=torch.float64, device='cuda') for _ in range(3)) for _ in range(2)]
+        torch.cuda.synchronize()
+        for rep in range(3):                        # 6 launches queued on two streams before anything is waited for
+            for k in range(2):
+                ctxs[k].intersect(rays[k], static=True, out=outs[k], stream=streams[k].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert int((ref[k][0] >= 0).sum()) > n // 4
+            for a, b in zip(ref[k], outs[k]):
+                assert torch.equal(a, b)
+    finally:
+        for k in ('PT_TRACE_PAIR', 'PT_PAIR_LDS_LEVELS'):
+            del os.environ[k]
+        for c in ctxs:
+            c.close()
