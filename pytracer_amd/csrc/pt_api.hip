@@ -35,6 +35,7 @@ struct pt_ctx {
     bool have_scene;
     DScene sc;
     void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf, *d_tri_cls, *d_frames;
+    void *d_meta;            // packed (offset, n_prim | axis) words of all nodes (DScene::node_meta)
     void *d_pairs;           // GPair records of the interior nodes (k_trace_pair)
     int n_pairs;
     int use_pair;            // PT_TRACE_PAIR: 0 never, 1 always, unset (-1) = by tree size (launch_trace)
@@ -51,6 +52,14 @@ struct pt_ctx {
                              // only (measured: closest -6 %, any +5 %), 2 both
     int stack_need;          // deepest leaf = max simultaneous todo entries (bvh.py:332 allows 64)
     bool has_spec_reflect;   // any material with a SpecularReflection lobe (Direct recursion)
+    bool diffuse_back;       // hits listed in two classes by lobe set, the back list shaded by the diffuse-only kernel
+    int sort_rays;           // PT_SORT_RAYS: bit 0 / bit 1 = the continuation / shadow rays of a render are binned by origin cell and
+                             // octant before k_trace_pair(_refill) traces them (k_sort_rays); unset (-1) = by tree size
+    int sort_window, sort_mode;   // PT_SORT_WINDOW (entries per sorted window), PT_SORT_MODE (key arrangement | grid bits << 4)
+    int *order_q, *order_sh[2];   // [cap] / [sh_cap]: trace order of the continuation queue / the two shadow queues
+    int lobe_sets;           // PT_SHADE_LOBESETS: 1 = the diffuse class is shaded by the kernel compiled for it; 0 = the classes only
+                             // order the hit lists and one kernel shades both
+    bool all_diffuse;        // no material has a Blinn / Fresnel / specular / measured lobe: the diffuse-only kernel alone
     int light_ns[16];
     int shadow_per_vertex_direct;
     // workspace (device), sized for `cap` paths per batch
@@ -201,6 +210,14 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     if (const char *e = getenv("PT_TRACE_PACKET")) c->use_packet = atoi(e);
     if (const char *e = getenv("PT_PAIR_REFILL")) c->pair_refill = atoi(e);
     if (const char *e = getenv("PT_REFILL_MIN")) c->refill_min = atoi(e);
+    c->sort_rays = -1;
+    if (const char *e = getenv("PT_SORT_RAYS")) c->sort_rays = atoi(e);
+    c->sort_window = 4096;
+    if (const char *e = getenv("PT_SORT_WINDOW")) c->sort_window = atoi(e);
+    c->sort_mode = 0;
+    if (const char *e = getenv("PT_SORT_MODE")) c->sort_mode = atoi(e);
+    c->lobe_sets = 1;
+    if (const char *e = getenv("PT_SHADE_LOBESETS")) c->lobe_sets = atoi(e);
     c->shade_dynamic = -1;
     if (const char *e = getenv("PT_SHADE_DYNAMIC")) c->shade_dynamic = atoi(e);
     if (const char *e = getenv("PT_TRACE_DYNAMIC")) c->trace_dynamic = atoi(e);
@@ -312,7 +329,7 @@ extern "C" int pt_launch_log(pt_ctx *c, pt_launch_record *out, int32_t cap, int3
 
 static void free_scene(pt_ctx *c) {
     void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top,
-                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill, &c->d_tri_cls, &c->d_frames};
+                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill, &c->d_tri_cls, &c->d_frames, &c->d_meta};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -648,6 +665,11 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
         }
     }
     HIPCHK(c, upload(&c->d_nodes, nodes.data(), nodes.size()));
+    {
+        std::vector<int32_t> meta(2 * ((size_t)d->n_nodes + 1), 0);      // padded to a whole int4
+        for (int i = 0; i < d->n_nodes; i++) { meta[2 * (size_t)i] = nodes[i].offset; meta[2 * (size_t)i + 1] = nodes[i].nprim_axis; }
+        HIPCHK(c, upload(&c->d_meta, meta.data(), meta.size()));
+    }
     // top of the tree for k_trace_top: the first K nodes in breadth-first order, K from the LDS left
     // beside 1024 per-lane stacks (160 KB per CU on gfx950)
     int n_top = 0;
@@ -702,6 +724,7 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     rc = upload_brdf_tables(c, d, mats);
     if (rc != PT_OK) return rc;
     HIPCHK(c, upload(&c->d_mats, mats.data(), mats.size()));
+    c->diffuse_back = c->all_diffuse = false;
     if (c->d_brdf && d->n_tris > 0 && !getenv("PT_NO_HIT_CLASSES")) {
         // per triangle: does its material carry a measured lobe?  k_list_hits lists those hits apart (pt_kernels.h HitList)
         std::vector<unsigned char> cls((size_t)d->n_tris, 0);
@@ -711,6 +734,22 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
                 if (m.lobes[l].type == PT_LOBE_MEASURED_IRISO) cls[(size_t)i] = 1;
         }
         HIPCHK(c, upload(&c->d_tri_cls, cls.data(), cls.size()));
+    } else if (!c->d_brdf && d->n_tris > 0 && !getenv("PT_NO_HIT_CLASSES")) {
+        // Shading by lobe set (material.py:122-141 Matte against :166-189, :329-364 ...): the class of a material is
+        // the set of lobe types it can push; a triangle whose material has diffuse lobes only (Lambert, Oren-Nayar)
+        // is class 0 and its hits are shaded by the kernel compiled without the other lobes (pt_kernels.hip k_shade).
+        std::vector<unsigned char> mat_general((size_t)d->n_materials, 0);
+        for (int i = 0; i < d->n_materials; i++)
+            for (int l = 0; l < mats[(size_t)i].n_lobes; l++)
+                if (!((PT_LOBES_DIFFUSE >> mats[(size_t)i].lobes[l].type) & 1)) mat_general[(size_t)i] = 1;
+        std::vector<unsigned char> cls((size_t)d->n_tris, 0);
+        long n_general = 0;
+        for (int i = 0; i < d->n_tris; i++) n_general += (cls[(size_t)i] = mat_general[(size_t)d->tri_mat[i]]);
+        if (n_general == 0) c->all_diffuse = true;
+        else if (n_general < d->n_tris) {
+            c->diffuse_back = true;
+            HIPCHK(c, upload(&c->d_tri_cls, cls.data(), cls.size()));
+        }
     }
     HIPCHK(c, upload(&c->d_lights, d->lights, (size_t)d->n_lights));
     if (d->n_textures > 0) {
@@ -723,6 +762,7 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     if (d->tri_uv && d->n_tris > 0) HIPCHK(c, upload(&c->d_uv, d->tri_uv, 6 * (size_t)d->n_tris));
     DScene &s = c->sc;
     s.nodes = (const GNode *)c->d_nodes;
+    s.node_meta = (const int2 *)c->d_meta;
     s.pairs = (const GPair *)c->d_pairs;
     s.top = n_top ? (const TopNode *)c->d_top : nullptr;
     s.n_top = n_top;
@@ -783,10 +823,18 @@ static int trace_grid(pt_ctx *c, long n, bool any) {
     return (int)std::max<long>(1, std::min(blocks, cap));
 }
 
+// would a non-packet trace launch of this kind run k_trace_pair(_refill)?  (the kernels that can trace through `order`)
+static bool trace_uses_pair(const pt_ctx *c, bool any) {
+    int use_pair = c->use_pair;
+    if (use_pair < 0) use_pair = c->meta_stack > 0 ? 0 : 3;
+    return c->d_pairs && c->n_pairs > 0 && c->d_spill && (use_pair & (any ? 2 : 1));
+}
+
 // every trace launch goes through here: top-of-tree kernel when the tree qualified at upload
 static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t stream, const double *rays, long stride,
                                const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t, double *out_b1,
-                               double *out_b2, const ShadowResolve &rs, unsigned long long *counters, int *kid = nullptr) {
+                               double *out_b2, const ShadowResolve &rs, unsigned long long *counters, int *kid = nullptr,
+                               const int *order = nullptr) {
     int kid_dummy;
     if (!kid) kid = &kid_dummy;
     // children-pair walk (PT_TRACE_PAIR: bit 0 = closest-hit launches, bit 1 = any-hit launches; unset: by tree size)
@@ -826,7 +874,7 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
         *kid = (seg_counts && refill && (n_val & PT_TRACE_DYNAMIC)) ? PT_KERNEL_TRACE_PAIR_REFILL : PT_KERNEL_TRACE_PAIR;
         return pt_launch_trace_pair(any, c->pair_lds_levels, spill, (int)grid, stream, c->sc, rays, stride, seg_counts,
                                     seg, (seg_counts && refill) ? (n_val | PT_TRACE_REFILL) : n_val, out_prim, out_t, out_b1, out_b2, rs, counters,
-                                    c->refill_min);
+                                    c->refill_min, order);
     }
     if (c->meta_stack > 0 && c->use_top <= 0 && (c->use_meta > 1 || (c->use_meta == 1 && !any))) {
         const long blocks = (n_bound + 1023) / 1024;
@@ -986,6 +1034,7 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv, int gshift) {
     size_t off_img = need(2 * cap * sizeof(double));
     size_t off_hit = need(cap * sizeof(int));
     size_t off_esc = need(cap * sizeof(int));
+    size_t off_oq = need(cap * sizeof(int)), off_osh[2] = {need(sh_cap * sizeof(int)), need(sh_cap * sizeof(int))};
     HIPCHK(c, hipMalloc(&c->ws, bytes));
     char *b = (char *)c->ws;
     for (int k = 0; k < 2; k++) {
@@ -1004,6 +1053,8 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv, int gshift) {
     c->st.esc = (int *)(b + off_esc);
     c->st.stride = cap;
     c->hit_idx = (int *)(b + off_hit);
+    c->order_q = (int *)(b + off_oq);
+    for (int k = 0; k < 2; k++) c->order_sh[k] = (int *)(b + off_osh[k]);
     c->cap = cap; c->sh_cap = sh_cap; c->ws_bytes = bytes;
     return PT_OK;
 }
@@ -1147,6 +1198,14 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     // Counter blocks of the hit lists alternate with the level: k_list_hits(k) fills block k & 1 and resets the other
     // one for level k + 1 (nothing has touched it since k_shade(k - 1) ended); k_raygen resets block 0.
     auto hit_count = [&](int level) { return c->d_counts + ((level & 1) ? 5 : 3) * PT_CNT_BLOCK; };
+    // ray binning (k_sort_rays) for the launches k_trace_pair(_refill) traces.  Default: off (measured).
+    int sort_rays = c->sort_rays < 0 ? 0 : c->sort_rays;
+    if (c->sc.n_nodes == 0 || !dyn) sort_rays = 0;
+    auto sorted = [&](bool any, hipStream_t s_, const double *rays, long stride, const int *counts, long seg, int *order) -> const int * {
+        if (!(sort_rays & (any ? 2 : 1)) || !trace_uses_pair(c, any)) return nullptr;
+        if (pt_launch_sort_rays(s_, c->sc, rays, stride, counts, seg, c->sort_window, c->sort_mode, order) != hipSuccess) return nullptr;
+        return order;
+    };
     auto hit_list = [&](int level) {
         HitList hl{};
         hl.idx = c->hit_idx; hl.count = hit_count(level);
@@ -1204,7 +1263,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
                 // done: the wait above / stream order) and the next level's hit list
                 HIPCHK(c, pt_launch_list_hits(gs * 2, stream, qin, hit_list(level), qout.count, sh.count, hit_count(level + 1)));
                 HIPCHK(c, pt_launch_shade(ig->kind, ig->shade_f32 != 0, gs, stream, c->sc, c->d_rc, base, level, qin,
-                                          hit_list(level), qout, sh, c->st));
+                                          hit_list(level), qout, sh, c->st, c->diffuse_back && c->lobe_sets, c->all_diffuse && c->lobe_sets));
             }
             ShadowResolve rs = {sh.c, sh.stride, sh.slot, c->st.L, c->st.stride};
             hipStream_t any_stream = stream;
@@ -1215,9 +1274,11 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             }
             {
                 StageTimer tm(c, any_stream, STAGE_TRACE_ANY, level, batch_no);
+                const bool pk = dyn && level == 0 && (use_packet & 2);
+                const int *ord = pk ? nullptr : sorted(true, any_stream, sh.rays, sh.stride, sh.count, sh.seg, c->order_sh[sb]);
                 HIPCHK(c, launch_trace(c, true, (long)nb * spv, any_stream, sh.rays, sh.stride, sh.count, sh.seg,
-                                       dyn | ((dyn && level == 0 && (use_packet & 2)) ? PT_TRACE_PACKET : 0), nullptr, nullptr,
-                                       nullptr, nullptr, rs, tm.counters(cnt), &kid));
+                                       dyn | (pk ? PT_TRACE_PACKET : 0), nullptr, nullptr,
+                                       nullptr, nullptr, rs, tm.counters(cnt), &kid, ord));
                 tm.set_kernel(kid);
             }
             if (ovl) {
@@ -1236,8 +1297,9 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             }
             if (level + 1 < levels) {
                 StageTimer tm(c, stream, STAGE_TRACE_CLOSEST, level + 1, batch_no);
+                const int *ord = sorted(false, stream, qout.rays, qout.stride, qout.count, qout.seg, c->order_q);
                 HIPCHK(c, launch_trace(c, false, nb, stream, qout.rays, qout.stride, qout.count, qout.seg, dyn, qout.prim,
-                                       qout.t, qout.b1, qout.b2, no_rs, tm.counters(cnt), &kid));
+                                       qout.t, qout.b1, qout.b2, no_rs, tm.counters(cnt), &kid, ord));
                 tm.set_kernel(kid);
                 cur ^= 1;
             }

@@ -140,6 +140,7 @@ struct DScene {
     const TopNode *top;        // the first n_top nodes in breadth-first order, (k_tri_frames at upload)
     int32_t n_top;
     int32_t exact_slab;        // a node box with min > max (or NaN): only the reference's own comparison order is exact
+    const int2 *node_meta;     // [n_nodes] (offset, n_prim | axis << 16) of every node, packed: what k_trace_meta stages in LDS
     const GTri *tris;
     const double *tri_verts;   // [n_tris][9] p1,p2,p3 for shading geometry
     const double *tri_frames;  // [n_tris][9] nn, sn, tn: the shading frame of every triangle (tri_frame), (k_tri_frames at upload)
@@ -603,14 +604,28 @@ __device__ __forceinline__ d3 measured_f(const char *base, bool in_lds, int tabl
     return in_lds ? measured_f_as<true>(base, table, wo, wi, hits) : measured_f_as<false>(base, table, wo, wi, hits);
 }
 
+// LOBES (here and below): the lobe types the calling kernel is compiled for.  k_shade is instantiated per LOBE SET:
+// hits are listed by the class of their material (pt_scene_upload: the lobe-type mask of every material), and the hits
+// on materials without Blinn / Fresnel / specular lobes — Matte, i.e. the head scene's backdrop and half of the
+// 10^6-triangle soup — are shaded by a kernel in which those lobes do not exist, at a fraction of the registers.
+// lobe_type<LOBES> returns the lobe's type restricted to the set, so that every switch below folds; for a material
+// of the class it is the identity, hence the same operations in the same order and the same bits.
+#define PT_LOBES_ALL 0x7F
+#define PT_LOBES_DIFFUSE ((1 << PT_LOBE_LAMBERT) | (1 << PT_LOBE_OREN_NAYAR))
+template <int LOBES> __device__ __forceinline__ int lobe_type(const pt_lobe &l) {
+    if (LOBES == PT_LOBES_DIFFUSE) return l.type == PT_LOBE_OREN_NAYAR ? PT_LOBE_OREN_NAYAR : PT_LOBE_LAMBERT;
+    return l.type;
+}
+
 // EXT (here and below): the shade kernels that scenes with measured lobes run (k_shade<KIND, 2>, pt_launch_shade);
 // the measured lobe is compiled into those only, so that the other kernels keep their registers
-template <bool EXT, typename R>
+template <bool EXT, typename R, int LOBES = PT_LOBES_ALL>
 __device__ inline v3<R> lobe_f(const pt_lobe &l, v3<R> wo, v3<R> wi, const VertexT<R> &vx) {
     v3<R> Rc = mkv<R>((R)l.R[0], (R)l.R[1], (R)l.R[2]);
-    if (EXT && l.type == PT_LOBE_MEASURED_IRISO)      // the table walk is binary64 in every variant
+    const int type = lobe_type<LOBES>(l);
+    if (EXT && type == PT_LOBE_MEASURED_IRISO)      // the table walk is binary64 in every variant
         return cvt3<R>(measured_f(vx.brdf, vx.brdf_in_lds, (int)l.a, cvt3<double>(wo), cvt3<double>(wi), vx.hits));
-    switch (l.type) {
+    switch (type) {
     case PT_LOBE_LAMBERT:   // bdf.py:327-332
         return Rc * R(PT_INV_PI);
     case PT_LOBE_OREN_NAYAR: {   // orennayar.py:44-62
@@ -636,7 +651,7 @@ __device__ inline v3<R> lobe_f(const pt_lobe &l, v3<R> wo, v3<R> wi, const Verte
         R gm = (g2 < g1) ? g2 : g1;
         R G = (gm < R(1)) ? gm : R(1);
         R D = ((R)l.c + R(2)) * R(PT_INV_2PI) * r_pow(awh, (R)l.c);
-        if (l.type == PT_LOBE_MICROFACET_BLINN_COND) {   // Spectrum-valued Fresnel term (MetalMaterial)
+        if (type == PT_LOBE_MICROFACET_BLINN_COND) {   // Spectrum-valued Fresnel term (MetalMaterial)
             const R ch = r_abs(ct_h);
             v3<R> F = mkv<R>(fr_cond(ch, (R)l.eta[0], (R)l.k[0]), fr_cond(ch, (R)l.eta[1], (R)l.k[1]),
                              fr_cond(ch, (R)l.eta[2], (R)l.k[2]));
@@ -651,9 +666,9 @@ __device__ inline v3<R> lobe_f(const pt_lobe &l, v3<R> wo, v3<R> wi, const Verte
 }
 
 // BDF.pdf (bdf.py:97-106), Microfacet.pdf (torrance.py:225-228), specular → 0
-template <typename R>
+template <typename R, int LOBES = PT_LOBES_ALL>
 __device__ inline R lobe_pdf(const pt_lobe &l, v3<R> wo, v3<R> wi) {
-    switch (l.type) {
+    switch (lobe_type<LOBES>(l)) {
     case PT_LOBE_LAMBERT:
     case PT_LOBE_OREN_NAYAR:
     case PT_LOBE_MEASURED_IRISO:
@@ -667,11 +682,11 @@ __device__ inline R lobe_pdf(const pt_lobe &l, v3<R> wo, v3<R> wi) {
     }
 }
 
-template <bool EXT, typename R>
+template <bool EXT, typename R, int LOBES = PT_LOBES_ALL>
 __device__ inline R lobe_sample_f(const pt_lobe &l, v3<R> wo, R u1, R u2, v3<R> &wi_out, v3<R> &f_out,
                                   const VertexT<R> &vx) {
     v3<R> Rc = mkv<R>((R)l.R[0], (R)l.R[1], (R)l.R[2]);
-    switch (l.type) {
+    switch (lobe_type<LOBES>(l)) {
     case PT_LOBE_LAMBERT:
     case PT_LOBE_OREN_NAYAR:
     case PT_LOBE_MEASURED_IRISO: {
@@ -688,8 +703,8 @@ __device__ inline R lobe_sample_f(const pt_lobe &l, v3<R> wo, R u1, R u2, v3<R> 
         else wi.z = r_sqrt(max0(R(1) - wi.x * wi.x - wi.y * wi.y));
         if (wo.z < R(0)) wi.z *= R(-1);
         wi_out = wi;
-        f_out = lobe_f<EXT>(l, wo, wi, vx);
-        return lobe_pdf(l, wo, wi);
+        f_out = lobe_f<EXT, R, LOBES>(l, wo, wi, vx);
+        return lobe_pdf<R, LOBES>(l, wo, wi);
     }
     case PT_LOBE_MICROFACET_BLINN:
     case PT_LOBE_MICROFACET_BLINN_COND: {   // torrance.py:218-223, Blinn.sample_f :72-93
@@ -706,7 +721,7 @@ __device__ inline R lobe_sample_f(const pt_lobe &l, v3<R> wo, R u1, R u2, v3<R> 
         if (dwh <= R(0)) pdf = R(0);
         wi_out = wi;
         if (wi.z * wo.z <= R(0)) f_out = mkv<R>(R(0), R(0), R(0));
-        else f_out = lobe_f<EXT>(l, wo, wi, vx);
+        else f_out = lobe_f<EXT, R, LOBES>(l, wo, wi, vx);
         return pdf;
     }
     case PT_LOBE_SPEC_REFLECT: {   // bdf.py:251-256
@@ -735,33 +750,33 @@ __device__ inline R lobe_sample_f(const pt_lobe &l, v3<R> wo, R u1, R u2, v3<R> 
 }
 
 // BSDF.f, bsdf.py:207-224
-template <bool EXT, typename R>
+template <bool EXT, typename R, int LOBES = PT_LOBES_ALL>
 __device__ inline v3<R> bsdf_f(const VertexT<R> &vx, v3<R> wo_w, v3<R> wi_w, unsigned flags) {
     v3<R> wi = w2l(vx, wi_w), wo = w2l(vx, wo_w);
     if (dot3(wi_w, vx.nn) * dot3(wo_w, vx.nn) > R(0)) flags &= ~BDF_TRANSMISSION;
     else flags &= ~BDF_REFLECTION;
     v3<R> f = mkv<R>(R(0), R(0), R(0));
     for (int i = 0; i < vx.mat->n_lobes; i++)
-        if (match_flag(vx.mat->lobes[i].type, flags)) f = f + lobe_f<EXT>(vx.mat->lobes[i], wo, wi, vx);
+        if (match_flag(lobe_type<LOBES>(vx.mat->lobes[i]), flags)) f = f + lobe_f<EXT, R, LOBES>(vx.mat->lobes[i], wo, wi, vx);
     return f;
 }
 
 // BSDF.pdf, bsdf.py:156-167
-template <typename R>
+template <typename R, int LOBES = PT_LOBES_ALL>
 __device__ inline R bsdf_pdf(const VertexT<R> &vx, v3<R> wo_w, v3<R> wi_w, unsigned flags) {
     if (vx.mat->n_lobes == 0) return R(0);
     v3<R> wo = w2l(vx, wo_w), wi = w2l(vx, wi_w);
     R pdf = R(0);
     int n_match = 0;
     for (int i = 0; i < vx.mat->n_lobes; i++)
-        if (match_flag(vx.mat->lobes[i].type, flags)) { n_match++; pdf += lobe_pdf(vx.mat->lobes[i], wo, wi); }
+        if (match_flag(lobe_type<LOBES>(vx.mat->lobes[i]), flags)) { n_match++; pdf += lobe_pdf<R, LOBES>(vx.mat->lobes[i], wo, wi); }
     return n_match > 0 ? pdf / n_match : R(0);
 }
 
 // BSDF.f and BSDF.pdf for the same pair of directions (estimate_direct evaluates both,
 // integrator/utility.py:221-231).  Same values as bsdf_f / bsdf_pdf; a Blinn microfacet lobe computes
 // its half vector and |cos θh|^e once for both (pow is the most expensive call of the vertex).
-template <bool EXT, typename R>
+template <bool EXT, typename R, int LOBES = PT_LOBES_ALL>
 __device__ inline v3<R> bsdf_f_pdf(const VertexT<R> &vx, v3<R> wo_w, v3<R> wi_w, unsigned flags, R &pdf_out) {
     v3<R> wi = w2l(vx, wi_w), wo = w2l(vx, wo_w);
     unsigned fflags = flags;
@@ -772,8 +787,9 @@ __device__ inline v3<R> bsdf_f_pdf(const VertexT<R> &vx, v3<R> wo_w, v3<R> wi_w,
     int n_match = 0;
     for (int i = 0; i < vx.mat->n_lobes; i++) {
         const pt_lobe &l = vx.mat->lobes[i];
-        const bool mf = match_flag(l.type, fflags), mp = match_flag(l.type, flags);
-        if (l.type == PT_LOBE_MICROFACET_BLINN && mf && mp && wi.z != R(0) && wo.z != R(0) && wi.z * wo.z > R(0)) {
+        const int type = lobe_type<LOBES>(l);
+        const bool mf = match_flag(type, fflags), mp = match_flag(type, flags);
+        if (type == PT_LOBE_MICROFACET_BLINN && mf && mp && wi.z != R(0) && wo.z != R(0) && wi.z * wo.z > R(0)) {
             // lobe_f and blinn_pdf share wh = normalize(wo + wi) (addition commutes) and pow(|wh.z|, e)
             v3<R> Rc = mkv<R>((R)l.R[0], (R)l.R[1], (R)l.R[2]);
             v3<R> wh = normalize3(wi + wo);
@@ -790,8 +806,8 @@ __device__ inline v3<R> bsdf_f_pdf(const VertexT<R> &vx, v3<R> wo_w, v3<R> wi_w,
             if (dwh > R(0)) pdf += (((R)l.c + R(1)) * pw) / (R(2) * R(PT_PI) * R(4) * dwh);
             continue;
         }
-        if (mf) f = f + lobe_f<EXT>(l, wo, wi, vx);
-        if (mp) { n_match++; pdf += lobe_pdf(l, wo, wi); }
+        if (mf) f = f + lobe_f<EXT, R, LOBES>(l, wo, wi, vx);
+        if (mp) { n_match++; pdf += lobe_pdf<R, LOBES>(l, wo, wi); }
     }
     pdf_out = n_match > 0 ? pdf / n_match : R(0);
     return f;
@@ -800,12 +816,12 @@ __device__ inline v3<R> bsdf_f_pdf(const VertexT<R> &vx, v3<R> wo_w, v3<R> wi_w,
 // BSDF.sample_f AS IT EXECUTES, bsdf.py:100-154: `bdf.type & SPECULAR` is an object, always
 // truthy, so the pdf sum (:132-135) and the f re-evaluation (:141-152) never run (Q2).
 // u_com picks the lobe: binary64 in every variant (a discrete decision).
-template <bool EXT, typename R>
+template <bool EXT, typename R, int LOBES = PT_LOBES_ALL>
 __device__ inline R bsdf_sample_f(const VertexT<R> &vx, v3<R> wo_w, R u0, R u1, double u_com, unsigned flags,
                                   v3<R> &wi_w, v3<R> &f) {
     const pt_material *m = vx.mat;
     int n_match = 0;
-    for (int i = 0; i < m->n_lobes; i++) n_match += match_flag(m->lobes[i].type, flags) ? 1 : 0;
+    for (int i = 0; i < m->n_lobes; i++) n_match += match_flag(lobe_type<LOBES>(m->lobes[i]), flags) ? 1 : 0;
     f = mkv<R>(R(0), R(0), R(0));
     wi_w = mkv<R>(R(0), R(0), R(0));
     if (n_match == 0) return R(0);
@@ -813,13 +829,13 @@ __device__ inline R bsdf_sample_f(const VertexT<R> &vx, v3<R> wo_w, R u0, R u1, 
     if (cnt > n_match - 1) cnt = n_match - 1;
     int pick = -1;
     for (int i = 0; i < m->n_lobes; i++)
-        if (match_flag(m->lobes[i].type, flags)) {
+        if (match_flag(lobe_type<LOBES>(m->lobes[i]), flags)) {
             if (cnt == 0) { pick = i; break; }
             cnt--;
         }
     if (pick < 0) return R(0);
     v3<R> wo = w2l(vx, wo_w), wi, fl;
-    R pdf = lobe_sample_f<EXT>(m->lobes[pick], wo, u0, u1, wi, fl, vx);
+    R pdf = lobe_sample_f<EXT, R, LOBES>(m->lobes[pick], wo, u0, u1, wi, fl, vx);
     if (pdf == R(0)) return R(0);
     wi_w = l2w(vx, wi);
     if (n_match > 1) pdf /= n_match;

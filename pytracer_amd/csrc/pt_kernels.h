@@ -91,12 +91,15 @@ struct HitList {
     int *esc;          // PathState::esc
     int add_escape;    // level > 0: a miss marks its path escaped (esc[slot] = 1); k_splat adds T * Σ light.le for it
     int dynamic;       // k_shade draws its 64-entry chunks from the region's cursor (PT_CNT_CURSOR) instead of striding
-    // Scenes with measured BRDF lobes: hits on such materials are listed from the FRONT of the region, the others from
-    // its BACK (second counter: element PT_CNT_BACK of the region's line), so that a shading wave holds one class only
-    // (the table walk of a measured lobe costs 5x a plain vertex and a wave pays its most expensive lane).  nullptr = one list.
-    const unsigned char *tri_cls;   // [n_tris] 1 = the triangle's material has a measured lobe
+    // Hit classes: hits on triangles of class 1 are listed from the FRONT of the region, the others from its BACK (second
+    // counter: element PT_CNT_BACK of the region's line), so that a shading wave holds one class only.  nullptr = one list.
+    // Scenes with measured BRDF lobes: class 1 = the material has a measured lobe (its table walk costs 5x a plain vertex
+    // and a wave pays its most expensive lane).  Other scenes: class 1 = the material has a Blinn / Fresnel / specular
+    // lobe, class 0 = diffuse lobes only, and the two lists are shaded by two kernels (pt_launch_shade).
+    const unsigned char *tri_cls;   // [n_tris]
 };
 #define PT_CNT_BACK 2
+#define PT_CNT_CURSOR2 3     // chunk cursor of the back list when the two lists are shaded by two launches (k_shade PART 2)
 
 struct ShadowResolve {
     const double *c;
@@ -168,7 +171,11 @@ int pt_trace_pair_occupancy(bool any, int lds_levels);
 hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid, hipStream_t stream, const DScene &sc,
                                 const double *rays, long stride, const int *seg_counts, long seg, int n_val, int *out_prim,
                                 double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
-                                unsigned long long *counters, int refill_min);
+                                unsigned long long *counters, int refill_min, const int *order);
+// order[region start + k] = the region-local entry to trace k-th: windows of `window` entries (a power of two <= 16384) sorted
+// by origin cell / direction octant (mode: low 4 bits = key arrangement, high bits = grid bits per axis, 0 = 4)
+hipError_t pt_launch_sort_rays(hipStream_t stream, const DScene &sc, const double *rays, long stride, const int *seg_counts,
+                               long seg, int window, int mode, int *order);
 hipError_t pt_launch_raygen(int grid, hipStream_t stream, const RenderConst *rc, long base, int nb, int gshift,
                             const Queue &q, const PathState &st, unsigned long long *counters, int *clr_hits);
 // clr0..2 (nullable): counter blocks (PT_CNT_BLOCK ints each) the kernel resets for the launches after it
@@ -176,7 +183,7 @@ hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, con
                                int *clr2);
 hipError_t pt_launch_shade(int kind, bool f32, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc,
                            long base, int level, const Queue &qin, const HitList &hl, const Queue &qout,
-                           const ShadowQueue &sh, const PathState &st);
+                           const ShadowQueue &sh, const PathState &st, bool diffuse_back, bool all_diffuse);
 hipError_t pt_launch_splat(hipStream_t stream, const RenderConst *rc, const pt_tile &tile, const pt_film_desc &fm,
                            long base, int nb, const PathState &st, double *film, double *sample_L,
                            unsigned long long *counters);

@@ -198,8 +198,12 @@ __device__ __forceinline__ void store_result(const TraceOut &o, long i, int res,
 // 1 with the claim for the NEXT chunk in flight while this one is traced (one VGPR held across the walk: its latency is
 // not in the loop), 2 claimed when needed, kept in a scalar register (k_trace_pair: a VGPR more costs its closest-hit
 // form the fifth wave per SIMD, 96 -> 103, and a chunk of its long walks takes 50x the claim's round trip).
+// `order` (segmented input only, nullable): entry k of a region is traced as entry order[region start + k] of that region
+// (k_sort_rays: the rays of a window binned by origin cell and direction, so that a wave's lanes and the waves of a CU
+// walk neighbouring parts of a tree that is far larger than the caches); results go to the ray's own index.
 template <int BLOCK, int DYN, class F>
-__device__ __forceinline__ unsigned for_each_ray(const int *__restrict__ seg_counts, long seg, int n_val, F one) {
+__device__ __forceinline__ unsigned for_each_ray(const int *__restrict__ seg_counts, long seg, int n_val, F one,
+                                                 const int *__restrict__ order = nullptr) {
     unsigned nray = 0;
     if (seg_counts) {
         const int lane = threadIdx.x & 63;
@@ -217,7 +221,7 @@ __device__ __forceinline__ unsigned for_each_ray(const int *__restrict__ seg_cou
             int k = dyn ? __builtin_amdgcn_readfirstlane(claim) : sub * 64;
             while (k < n) {
                 if (DYN == 1 && dyn) claim = lane == 0 ? atomicAdd(cursor, 64) : 0;
-                if (k + lane < n) { one(first + k + lane); nray++; }
+                if (k + lane < n) { one(first + (order ? order[first + k + lane] : k + lane)); nray++; }
                 if (DYN == 2 && dyn) claim = lane == 0 ? atomicAdd(cursor, 64) : 0;
                 k = dyn ? __builtin_amdgcn_readfirstlane(claim) : k + nsub * 64;
             }
@@ -395,8 +399,12 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_meta(DScene sc, const do
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     int2 *mlds = reinterpret_cast<int2 *>(s_mem);
     int *stack = reinterpret_cast<int *>(s_mem + pt_trace_meta_table_bytes(sc.n_nodes)) + threadIdx.x;
-    for (int k = threadIdx.x; k < sc.n_nodes; k += PT_TOP_BLOCK)
-        mlds[k] = make_int2(sc.nodes[k].offset, sc.nodes[k].nprim_axis);
+    {   // from the packed copy (8 bytes per node, 16-byte loads): read out of the 64-byte node records the staging of
+        // a 5.5 k-node tree fetched 354 KB per workgroup, 90 MB per launch
+        const int4 *src = reinterpret_cast<const int4 *>(sc.node_meta);
+        int4 *dst = reinterpret_cast<int4 *>(s_mem);
+        for (int k = threadIdx.x; k < (sc.n_nodes + 1) / 2; k += PT_TOP_BLOCK) dst[k] = src[k];
+    }
     __syncthreads();
     unsigned nvis = 0, ntri = 0;
     const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
@@ -688,7 +696,8 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair(DSc
                                                              int *__restrict__ out_prim, double *__restrict__ out_t,
                                                              double *__restrict__ out_b1, double *__restrict__ out_b2,
                                                              ShadowResolve rs, unsigned long long *counters,
-                                                             PairEnt *__restrict__ spill, int lds_levels) {
+                                                             PairEnt *__restrict__ spill, int lds_levels,
+                                                             const int *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     PairStack stack;
     stack.lds = reinterpret_cast<PairEnt *>(s_mem) + threadIdx.x;            // stack[level][thread], 8-byte entries
@@ -709,7 +718,7 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair(DSc
                                                 2 * stack.spill_stride);
         }
         store_result<ANY>(out, i, res, r, b1, b2);
-    });
+    }, order);
     if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
 }
 
@@ -730,7 +739,8 @@ template <bool ANY>
 __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair_refill(
     DScene sc, const double *__restrict__ rays, long stride, const int *__restrict__ seg_counts, long seg,
     int *__restrict__ out_prim, double *__restrict__ out_t, double *__restrict__ out_b1, double *__restrict__ out_b2,
-    ShadowResolve rs, unsigned long long *counters, PairEnt *__restrict__ spill, int lds_levels, int refill_min) {
+    ShadowResolve rs, unsigned long long *counters, PairEnt *__restrict__ spill, int lds_levels, int refill_min,
+    const int *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     PairStack stack;
     stack.lds = reinterpret_cast<PairEnt *>(s_mem) + threadIdx.x;
@@ -766,6 +776,7 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair_ref
                 if (!have) {
                     k = base + (int)lane_prefix(waiting);
                     if (k < n) {
+                        if (order) k = order[first + k];      // the claimed position's ray (k_sort_rays); k < n still holds
                         r = load_ray(rays, stride, first + k);
                         b1 = 0.; b2 = 0.;
                         result = ANY ? 0 : -1;
@@ -812,9 +823,10 @@ int pt_trace_pair_occupancy(bool any, int lds_levels) {
 hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid, hipStream_t stream, const DScene &sc,
                                 const double *rays, long stride, const int *seg_counts, long seg, int n_val, int *out_prim,
                                 double *out_t, double *out_b1, double *out_b2, const ShadowResolve &rs,
-                                unsigned long long *counters, int refill_min) {
+                                unsigned long long *counters, int refill_min, const int *order) {
     static bool attr_set[PT_MAX_DEVICES][2];
     const size_t lds = pt_trace_pair_lds(lds_levels);
+    if (!seg_counts) order = nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
     if (!attr_set[dev][any ? 1 : 0]) {
@@ -833,16 +845,94 @@ hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid,
     if (refill) {
         if (any)
             hipLaunchKernelGGL((k_trace_pair_refill<true>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride,
-                               seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, refill_min);
+                               seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, refill_min, order);
         else
             hipLaunchKernelGGL((k_trace_pair_refill<false>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride,
-                               seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, refill_min);
+                               seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, refill_min, order);
     } else if (any)
         hipLaunchKernelGGL((k_trace_pair<true>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride, seg_counts,
-                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels);
+                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, order);
     else
         hipLaunchKernelGGL((k_trace_pair<false>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride, seg_counts,
-                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels);
+                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, order);
+    return hipGetLastError();
+}
+
+// ---- ray binning for trees beyond the caches -----------------------------------------------------------------------
+// k_sort_rays: one workgroup per window of PT_SORT_WINDOW consecutive entries of a queue region.  Every ray gets a key —
+// the cell of its origin in a grid over the root box (Morton order) and the octant of its direction, arranged by `mode` —
+// and the window's entries are sorted by (key, position) with a bitonic network in LDS; order[region start + k] = the
+// region-local entry traced k-th.  Nothing moves: the trace kernels read rays and write results through `order`, the
+// stages after them keep the original positions.  Which entry a lane traces is not observable (results and census are
+// per ray), so the parity tests hold with the sort on and off.
+#define PT_SORT_THREADS 256
+__device__ __forceinline__ unsigned morton3(unsigned x, unsigned y, unsigned z) {       // 5 bits per axis
+    unsigned m = 0;
+    for (int b = 0; b < 5; b++) m |= (((x >> b) & 1u) << (3 * b)) | (((y >> b) & 1u) << (3 * b + 1)) | (((z >> b) & 1u) << (3 * b + 2));
+    return m;
+}
+__global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_rays(DScene sc, const double *__restrict__ rays, long stride,
+                                                               const int *__restrict__ seg_counts, long seg, int window,
+                                                               int mode, int *__restrict__ order) {
+    extern __shared__ unsigned s_keys[];
+    const int per_region = (int)((seg + window - 1) / window);
+    const int region = blockIdx.x / per_region, w = blockIdx.x % per_region;
+    const int n = seg_counts[region * PT_CNT_STRIDE];
+    const int k0 = w * window;
+    if (k0 >= n) return;                                   // wave-uniform: the whole workgroup leaves
+    const int m = min(window, n - k0);
+    const long first = (long)region * seg;
+    // grid over the root box: 2^bits cells per axis
+    const int bits = (mode >> 4) ? (mode >> 4) : 4;
+    const double G = (double)(1 << bits);
+    const double bx = sc.nodes[0].bmin[0], by = sc.nodes[0].bmin[1], bz = sc.nodes[0].bmin[2];
+    const double ix = G / (sc.nodes[0].bmax[0] - bx), iy = G / (sc.nodes[0].bmax[1] - by), iz = G / (sc.nodes[0].bmax[2] - bz);
+    const int idx_bits = 32 - __clz(window - 1);           // window is a power of two
+    for (int k = threadIdx.x; k < window; k += PT_SORT_THREADS) {
+        unsigned key = 0xFFFFFFFFu;
+        if (k < m) {
+            const long i = first + k0 + k;
+            const double ox = rays[i], oy = rays[stride + i], oz = rays[2 * stride + i];
+            const double dx = rays[3 * stride + i], dy = rays[4 * stride + i], dz = rays[5 * stride + i];
+            const int hi = (1 << bits) - 1;
+            const double fx = (ox - bx) * ix, fy = (oy - by) * iy, fz = (oz - bz) * iz;
+            const unsigned cx = (unsigned)(fx > 0. ? (fx < (double)hi ? (int)fx : hi) : 0);     // NaN -> 0
+            const unsigned cy = (unsigned)(fy > 0. ? (fy < (double)hi ? (int)fy : hi) : 0);
+            const unsigned cz = (unsigned)(fz > 0. ? (fz < (double)hi ? (int)fz : hi) : 0);
+            const unsigned mo = morton3(cx, cy, cz);
+            const unsigned oct = (dx < 0. ? 1u : 0u) | (dy < 0. ? 2u : 0u) | (dz < 0. ? 4u : 0u);
+            switch (mode & 15) {
+            case 1: key = (oct << (3 * bits)) | mo; break;          // octant major
+            case 2: key = mo; break;                                // origin only
+            case 3: key = oct; break;                               // octant only
+            default: key = (mo << 3) | oct; break;                  // origin cell, then octant
+            }
+            key = (key << idx_bits) | (unsigned)k;
+        }
+        s_keys[k] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= window; size <<= 1)
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < window / 2; t += PT_SORT_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const unsigned a = s_keys[i], b = s_keys[l];
+                const bool up = (i & size) == 0;
+                if ((a > b) == up) { s_keys[i] = b; s_keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    for (int k = threadIdx.x; k < m; k += PT_SORT_THREADS)
+        order[first + k0 + k] = k0 + (int)(s_keys[k] & (unsigned)(window - 1));
+}
+hipError_t pt_launch_sort_rays(hipStream_t stream, const DScene &sc, const double *rays, long stride, const int *seg_counts,
+                               long seg, int window, int mode, int *order) {
+    if (window < 64 || window > 16384 || (window & (window - 1))) return hipErrorInvalidValue;
+    const int bits = (mode >> 4) ? (mode >> 4) : 4;
+    if (bits < 1 || bits > 5 || 3 * bits + 3 + (32 - __builtin_clz(window - 1)) > 32) return hipErrorInvalidValue;
+    const long per_region = (seg + window - 1) / window;
+    hipLaunchKernelGGL(k_sort_rays, dim3((unsigned)(per_region * PT_SEG)), dim3(PT_SORT_THREADS), (size_t)window * sizeof(unsigned),
+                       stream, sc, rays, stride, seg_counts, seg, window, mode, order);
     return hipGetLastError();
 }
 
@@ -1224,6 +1314,7 @@ __device__ __forceinline__ void pt_clear_region_line(int *__restrict__ block, in
     block[r * PT_CNT_STRIDE] = 0;
     block[r * PT_CNT_STRIDE + PT_CNT_CURSOR] = 0;
     block[r * PT_CNT_STRIDE + PT_CNT_BACK] = 0;
+    block[r * PT_CNT_STRIDE + PT_CNT_CURSOR2] = 0;
 }
 
 // Where camera sample i of a batch goes in the segmented queue (pt_kernels.h): samples travel in
@@ -1323,7 +1414,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(const RenderConst *__restri
 
 // estimate_direct AS IT EXECUTES (integrator/utility.py:203-257; only the light-sampling half
 // contributes, Q3).  Returns true if a shadow ray must be traced; c = contribution if unoccluded.
-template <bool EXT, typename R>
+template <bool EXT, typename R, int LOBES>
 __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, const VertexT<R> &vx, v3<R> wo, R u0,
                                        R u1, Ray &shadow, d3 &c) {
     const unsigned flags = BDF_ALL & ~BDF_SPECULAR;
@@ -1332,7 +1423,7 @@ __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, con
     else delta_light_sample_l<R>(lt, vx.p, vx.rEps, ls);
     if (!(ls.pdf > R(0) && !util_is_black(ls.Li))) return false;
     R bp = R(0);
-    v3<R> f = (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) ? bsdf_f_pdf<EXT>(vx, wo, ls.wi, flags, bp) : bsdf_f<EXT>(vx, wo, ls.wi, flags);
+    v3<R> f = (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) ? bsdf_f_pdf<EXT, R, LOBES>(vx, wo, ls.wi, flags, bp) : bsdf_f<EXT, R, LOBES>(vx, wo, ls.wi, flags);
     if (util_is_black(f)) return false;
     R adot = r_abs(dot3(ls.wi, vx.nn));
     if (lt.kind != PT_LIGHT_DIFFUSE_SPHERE) {
@@ -1348,14 +1439,14 @@ __device__ inline bool estimate_direct(const DScene &sc, const pt_light &lt, con
 
 // One light of WhittedIntegrator.li (integrator/surface/whitted.py:44-53): no MIS, bsdf.f with the
 // default flags, Spectrum.is_black tests.  Returns true if a shadow ray must be traced.
-template <bool EXT, typename R>
+template <bool EXT, typename R, int LOBES>
 __device__ inline bool estimate_whitted(const DScene &sc, const pt_light &lt, const VertexT<R> &vx, v3<R> wo, R u0,
                                         R u1, Ray &shadow, d3 &c) {
     LightSampleT<R> ls;
     if (lt.kind == PT_LIGHT_DIFFUSE_SPHERE) sphere_light_sample_l<R>(lt, vx.p, vx.rEps, u0, u1, ls);
     else delta_light_sample_l<R>(lt, vx.p, vx.rEps, ls);
     if (spec_is_black(ls.Li) || ls.pdf == R(0)) return false;
-    v3<R> f = bsdf_f<EXT>(vx, wo, ls.wi, BDF_ALL);
+    v3<R> f = bsdf_f<EXT, R, LOBES>(vx, wo, ls.wi, BDF_ALL);
     if (spec_is_black(f)) return false;
     c = cvt3<double>((((f * ls.Li) * r_abs(dot3(ls.wi, vx.nn))) * R(1)) / ls.pdf);   // x transmittance (= 1) / pdf
     shadow = ls.shadow;
@@ -1394,10 +1485,15 @@ static_assert(sizeof(pt_material) % 8 == 0 && sizeof(pt_light) % 8 == 0, "copied
 // EXT (compile-time, so that plain scenes run the kernel unchanged): 0 = plain; 1 = the scene has textured lobes or
 // mesh uvs; 2 = it has measured BRDF lobes as well or instead
 // R: binary64 (parity; the reference's arithmetic) or binary32 (production only: BSDF / light arithmetic, pt_device.h)
-template <int KIND, int EXT, typename R>
-__global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT_SHADE_WAVES)) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
+// LOBES: the lobe types compiled in (pt_device.h lobe_type).  PART: which of the region's two hit lists this launch walks —
+// 0 both (one class, or scenes listed in one list), 1 the front list, 2 the back list (its own cursor: PT_CNT_CURSOR2).
+#ifndef PT_SHADE_WAVES_DIFFUSE
+#define PT_SHADE_WAVES_DIFFUSE 2      // 205-226 VGPRs, no scratch; at 3 waves per SIMD (168 VGPRs) it spills 140-220 bytes: shade 14.0 -> 15.1 ms
+#endif
+template <int KIND, int EXT, typename R, int LOBES>
+__global__ __launch_bounds__(PT_BLOCK, (LOBES != PT_LOBES_ALL ? PT_SHADE_WAVES_DIFFUSE : sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT_SHADE_WAVES)) void k_shade(DScene sc, const RenderConst *__restrict__ rcp, long base,
                                                     int level, Queue qin, HitList hl, Queue qout, ShadowQueue sh,
-                                                    PathState st) {
+                                                    PathState st, int part) {
     const RenderConst &rc = *rcp;
     // measured BRDF tables: the grid walk of measured_f is a chain of dependent loads (cell start -> samples), and at
     // 2 waves/SIMD nothing hides their latency: from LDS the 128 spp C5 render shades 2.5x faster than from L2
@@ -1443,15 +1539,16 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
     const int n_front = hl.count[region * PT_CNT_STRIDE], n_back = hl.count[region * PT_CNT_STRIDE + PT_CNT_BACK];
     const int n_fpad = (n_front + 63) & ~63;
     const int nloop = n_fpad + ((n_back + 63) & ~63);   // whole waves stay convergent for the ballots
+    const int lo = part == 2 ? n_fpad : 0, hi = part == 1 ? n_fpad : nloop;
     const long first = (long)region * qin.seg;
     // chunk kb of the region's hit list: the static stride, or (hl.dynamic) the next claim on the region's cursor — a
     // claim when needed, held in a scalar register: this kernel has no VGPR to carry a claim across the vertex code
     const int lane = (int)(threadIdx.x & 63);
-    int *cursor = hl.count + region * PT_CNT_STRIDE + PT_CNT_CURSOR;
+    int *cursor = hl.count + region * PT_CNT_STRIDE + (part == 2 ? PT_CNT_CURSOR2 : PT_CNT_CURSOR);
     auto next_chunk = [&](int kb) {
-        return hl.dynamic ? __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(cursor, 64) : 0) : kb + nsub * 64;
+        return hl.dynamic ? lo + __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(cursor, 64) : 0) : kb + nsub * 64;
     };
-    for (int kb = hl.dynamic ? next_chunk(0) : sub * 64; kb < nloop; kb = next_chunk(kb)) {
+    for (int kb = hl.dynamic ? next_chunk(0) : lo + sub * 64; kb < hi; kb = next_chunk(kb)) {
         const int k = kb + lane;
         const bool is_back = k >= n_fpad;
         const bool live = is_back ? (k - n_fpad < n_back) : (k < n_front);
@@ -1496,7 +1593,7 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
                 Ray sr;
                 d3 c = mk3(0, 0, 0);
                 if (hit) {
-                    need = estimate_whitted<EXT == 2, R>(sc, lights_p[li], vx, wo, (R)hash_uniform(ss.msid, k),
+                    need = estimate_whitted<EXT == 2, R, LOBES>(sc, lights_p[li], vx, wo, (R)hash_uniform(ss.msid, k),
                                                          (R)hash_uniform(ss.msid, k + 1), sr, c);
                     c = T * c;
                 }
@@ -1515,7 +1612,7 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
                     if (hit) {
                         double u0, u1;
                         direct_light_uv(ss, off, ns, j, perm, u0, u1);
-                        need = estimate_direct<EXT == 2, R>(sc, lights_p[li], vx, wo, (R)u0, (R)u1, sr, c);
+                        need = estimate_direct<EXT == 2, R, LOBES>(sc, lights_p[li], vx, wo, (R)u0, (R)u1, sr, c);
                         c = T * (c / (double)ns);
                     }
                     push_shadow(sh, region, need, sr, c, slot);
@@ -1526,7 +1623,7 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
             // specular_reflect, integrator/utility.py:120-155 (shared by Direct and Whitted)
             if (hit && (level + 1 < rc.ig.max_depth)) {
                 v3<R> wi, f;
-                R pdf = bsdf_sample_f<EXT == 2, R>(vx, wo, R(0), R(0), 0., BDF_REFLECTION | BDF_SPECULAR, wi, f);
+                R pdf = bsdf_sample_f<EXT == 2, R, LOBES>(vx, wo, R(0), R(0), 0., BDF_REFLECTION | BDF_SPECULAR, wi, f);
                 R adot = r_abs(dot3(wi, vx.nn));
                 if (pdf > R(0) && !util_is_black(f) && adot != R(0)) {
                     T = T * cvt3<double>((f * adot) / pdf);
@@ -1558,7 +1655,7 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
                 }
                 int ln = (int)floor(ulnum * sc.n_lights);
                 if (ln > sc.n_lights - 1) ln = sc.n_lights - 1;
-                need = estimate_direct<EXT == 2, R>(sc, lights_p[ln], vx, wo, (R)u0, (R)u1, sr, c);
+                need = estimate_direct<EXT == 2, R, LOBES>(sc, lights_p[ln], vx, wo, (R)u0, (R)u1, sr, c);
                 c = T * (c * (double)sc.n_lights);
             }
             push_shadow(sh, region, need, sr, c, slot);
@@ -1575,7 +1672,7 @@ __global__ __launch_bounds__(PT_BLOCK, (sizeof(R) == 4 ? PT_SHADE_WAVES_F32 : PT
                     uc = hash_uniform(ss.msid, kk + 2);
                 }
                 v3<R> wi, f;
-                R pdf = bsdf_sample_f<EXT == 2, R>(vx, wo, (R)u0, (R)u1, uc, BDF_ALL, wi, f);
+                R pdf = bsdf_sample_f<EXT == 2, R, LOBES>(vx, wo, (R)u0, (R)u1, uc, BDF_ALL, wi, f);
                 if (!(spec_is_black(f) || pdf == R(0))) {
                     T = T * cvt3<double>((f * r_abs(dot3(wi, vx.nn))) / pdf);
                     cont = true;
@@ -1687,9 +1784,12 @@ hipError_t pt_launch_list_hits(int grid, hipStream_t stream, const Queue &q, con
     return hipGetLastError();
 }
 
+// `diffuse_back`: the scene's hits are listed in two classes by lobe set (HitList::tri_cls: front = materials with Blinn /
+// Fresnel / specular lobes, back = the others) and the back list is shaded by the kernel compiled for PT_LOBES_DIFFUSE.
+// `all_diffuse`: no material of the scene has any other lobe: one list, the diffuse kernel alone.
 hipError_t pt_launch_shade(int kind, bool f32, int grid, hipStream_t stream, const DScene &sc, const RenderConst *rc,
                            long base, int level, const Queue &qin, const HitList &hl, const Queue &qout,
-                           const ShadowQueue &sh, const PathState &st) {
+                           const ShadowQueue &sh, const PathState &st, bool diffuse_back, bool all_diffuse) {
     grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
     // the measured variants take up to PT_MEAS_LDS_MAX of dynamic LDS (hit lists + table blob): beyond the 64 KB a
     // kernel gets by default, so the limit is raised once per device and kernel
@@ -1700,25 +1800,33 @@ hipError_t pt_launch_shade(int kind, bool f32, int grid, hipStream_t stream, con
         !attr_set[dev][kind][f32 ? 1 : 0]) {
         const void *fn;
         if (f32)
-            fn = kind == PT_INTEG_DIRECT ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_DIRECT, 2, float>)
-               : kind == PT_INTEG_WHITTED ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_WHITTED, 2, float>)
-                                          : reinterpret_cast<const void *>(&k_shade<PT_INTEG_PATH, 2, float>);
+            fn = kind == PT_INTEG_DIRECT ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_DIRECT, 2, float, PT_LOBES_ALL>)
+               : kind == PT_INTEG_WHITTED ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_WHITTED, 2, float, PT_LOBES_ALL>)
+                                          : reinterpret_cast<const void *>(&k_shade<PT_INTEG_PATH, 2, float, PT_LOBES_ALL>);
         else
-            fn = kind == PT_INTEG_DIRECT ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_DIRECT, 2, double>)
-               : kind == PT_INTEG_WHITTED ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_WHITTED, 2, double>)
-                                          : reinterpret_cast<const void *>(&k_shade<PT_INTEG_PATH, 2, double>);
+            fn = kind == PT_INTEG_DIRECT ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_DIRECT, 2, double, PT_LOBES_ALL>)
+               : kind == PT_INTEG_WHITTED ? reinterpret_cast<const void *>(&k_shade<PT_INTEG_WHITTED, 2, double, PT_LOBES_ALL>)
+                                          : reinterpret_cast<const void *>(&k_shade<PT_INTEG_PATH, 2, double, PT_LOBES_ALL>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PT_MEAS_LDS_MAX);
         if (e != hipSuccess) return e;
         attr_set[dev][kind][f32 ? 1 : 0] = true;
     }
-#define PT_SHADE(K, T, R) hipLaunchKernelGGL((k_shade<K, T, R>), dim3(grid), dim3(PT_BLOCK), (T) == 2 ? (size_t)sc.brdf_lds_bytes + PT_MEAS_HITS * PT_BLOCK * sizeof(int) : 0, stream, sc, rc, base, level, qin, hl, qout, sh, st)
+#define PT_SHADE(K, T, R, LB, PART) hipLaunchKernelGGL((k_shade<K, T, R, LB>), dim3(grid), dim3(PT_BLOCK), (T) == 2 ? (size_t)sc.brdf_lds_bytes + PT_MEAS_HITS * PT_BLOCK * sizeof(int) : 0, stream, sc, rc, base, level, qin, hl, qout, sh, st, PART)
     const int ext = sc.brdf != nullptr ? 2 : ((sc.textures != nullptr || sc.tri_uv != nullptr) ? 1 : 0);
-#define PT_SHADE_EXT(K) do { if (f32) { if (ext == 2) PT_SHADE(K, 2, float); else if (ext == 1) PT_SHADE(K, 1, float); else PT_SHADE(K, 0, float); } \
-                             else { if (ext == 2) PT_SHADE(K, 2, double); else if (ext == 1) PT_SHADE(K, 1, double); else PT_SHADE(K, 0, double); } } while (0)
+    // measured scenes keep their own two classes (measured lobes in front) and one kernel for both
+#define PT_SHADE_R(K, R) do { \
+        if (ext == 2) PT_SHADE(K, 2, R, PT_LOBES_ALL, 0); \
+        else if (all_diffuse) { if (ext == 1) PT_SHADE(K, 1, R, PT_LOBES_DIFFUSE, 0); else PT_SHADE(K, 0, R, PT_LOBES_DIFFUSE, 0); } \
+        else if (diffuse_back) { \
+            if (ext == 1) { PT_SHADE(K, 1, R, PT_LOBES_ALL, 1); PT_SHADE(K, 1, R, PT_LOBES_DIFFUSE, 2); } \
+            else { PT_SHADE(K, 0, R, PT_LOBES_ALL, 1); PT_SHADE(K, 0, R, PT_LOBES_DIFFUSE, 2); } \
+        } else { if (ext == 1) PT_SHADE(K, 1, R, PT_LOBES_ALL, 0); else PT_SHADE(K, 0, R, PT_LOBES_ALL, 0); } } while (0)
+#define PT_SHADE_EXT(K) do { if (f32) PT_SHADE_R(K, float); else PT_SHADE_R(K, double); } while (0)
     if (kind == PT_INTEG_DIRECT) PT_SHADE_EXT(PT_INTEG_DIRECT);
     else if (kind == PT_INTEG_WHITTED) PT_SHADE_EXT(PT_INTEG_WHITTED);
     else PT_SHADE_EXT(PT_INTEG_PATH);
 #undef PT_SHADE_EXT
+#undef PT_SHADE_R
 #undef PT_SHADE
     return hipGetLastError();
 }

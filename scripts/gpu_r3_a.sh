@@ -4,7 +4,7 @@
 set -o pipefail
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r3a_tests.log 2>&1 || { tail -60 gpurun_out/r3a_tests.log; exit 1; }
+timeout -k 10 900 python -u -m pytest tests/test_zz_bench_contract.py tests/test_zz_no_alloc.py -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r3a_tests.log 2>&1 || { tail -60 gpurun_out/r3a_tests.log; exit 1; }
 tail -3 gpurun_out/r3a_tests.log
 timeout -k 10 300 python bench.py --steps 10 --warmup 3 > gpurun_out/r3a_c3.json 2> gpurun_out/r3a.err || { tail gpurun_out/r3a.err; exit 1; }
 timeout -k 10 300 python bench.py --steps 8 --warmup 2 --shard-of 2,4,8 --no-cpu-baseline > gpurun_out/r3a_proxy.json 2>> gpurun_out/r3a.err || { tail gpurun_out/r3a.err; exit 1; }

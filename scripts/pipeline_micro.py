@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Feasibility of software-pipelined half-renders: P contexts on ONE GPU render the P interleaved-row shards of the
-headline job concurrently on P (x2) streams into one film; time per whole image against the one-context render."""
+headline job concurrently on P (x2) streams into one film; time per whole image against the one-context render.
+With an argument K the job is shard 0 of K (what one rank of a K-GPU run renders), split into P sub-shards."""
 import os
 import sys
 import time
@@ -22,12 +23,13 @@ smp = pa.sampler_desc(0, res, 0, res, xs, xs, True, 0)
 integ = pa.integrator_desc(A.PT_INTEG_PATH, 5, False)
 acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
 sums = {}
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 for P in (1, 2, 3, 4):
     ctxs = [Context(0) for _ in range(P)]
     for c in ctxs:
         c.upload(flat)
     streams = [torch.cuda.Stream() for _ in range(P)]
-    tiles = [shard_tile(smp, r, P, 'interleaved') for r in range(P)]
+    tiles = [shard_tile(smp, r * K, P * K, 'interleaved') for r in range(P)]      # rows r K, r K + P K, ...
 
     def step():
         acc.zero_()
@@ -43,6 +45,6 @@ for P in (1, 2, 3, 4):
         step()
     dt = (time.perf_counter() - t) / n
     sums[P] = float(acc.sum().item())
-    print('P = %d concurrent shard renders: %.2f ms per image, film sum %.10e' % (P, dt * 1e3, sums[P]), flush=True)
+    print('K = %d, P = %d concurrent shard renders: %.3f ms per job, film sum %.10e' % (K, P, dt * 1e3, sums[P]), flush=True)
     for c in ctxs:
         c.close()

@@ -2,7 +2,10 @@
 (a) as the multi-GPU job: the K shards `renderer.shard_tile` hands to K ranks, rendered one after another on one
 GPU, add up to the one-rank film (what bench.py --gpus K reduces over RCCL; the reference's hook is
 Sampler.compute_subwindow, sampler/sampler/__init__.py:87-111), for both shard modes;
-(b) one window of the full-size render against the oracle, per sample (1e-9) and on the film."""
+(b) one window of the full-size render against the oracle, per sample (1e-9) and on the film;
+(c) the WHOLE default render — one 2^26-path batch, k_trace_packet at level 0, k_trace_meta below, chunk cursors, two
+streams: the kernels and the schedule the headline number is measured on, at the size they run at — with per-sample
+radiance kept for all 67 M samples, of which three windows' rows are compared with the oracle (1e-9)."""
 import os
 
 import numpy as np
@@ -87,3 +90,42 @@ def test_c3_full_size_window_against_the_oracle(c3):
         for k in ('camera_samples', 'rays_closest', 'rays_any'):
             assert sg.as_dict()[k] == so.as_dict()[k], k
         assert sg.camera_samples == n
+
+
+WINDOWS = ((560, 300, 24, 24, 1, 0), (180, 700, 24, 24, 1, 0), (560, 300, 24, 40, 3, 1))
+
+
+def test_c3_whole_default_render_rows_against_the_oracle(c3):
+    """Not by transitivity: the production-default launch path at full size, against the oracle directly."""
+    import oracle_lib as O
+    torch, ctx, flat, cam, film, smp, integ = c3
+    osc = O.OracleScene(flat)
+    spp = XS * XS
+    full = pa.tile_desc(0, RES, 0, RES, 0, spp)
+    acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
+    L = torch.empty((RES * RES * spp, 3), dtype=torch.float64, device='cuda')        # 1.6 GB
+    ctx.set_profiling(1)
+    try:
+        sg = A.pt_stats()
+        ctx.render(cam, film, smp, integ, full, acc, sample_L=L, stats=sg)
+        torch.cuda.synchronize()
+        log = ctx.launch_log()
+    finally:
+        ctx.set_profiling(0)
+    # the launch path really is the production default: one batch, level 0 per wave, the rest k_trace_meta / k_trace
+    traces = [r for r in log if r['stage'].startswith('trace')]
+    assert {r['batch'] for r in log} == {0}
+    assert [r['kernel'] for r in traces if r['level'] == 0] == ['k_trace_packet', 'k_trace_packet']
+    assert {r['kernel'] for r in traces if r['level'] > 0 and r['stage'] == 'trace_closest'} == {'k_trace_meta'}
+    assert sum(r['rays'] for r in traces) == sg.rays_closest + sg.rays_any
+    assert sum(r['node_visits'] for r in traces) == sg.node_visits and sg.camera_samples == RES * RES * spp
+    for (x0, y0, w, h, step, phase) in WINDOWS:
+        wt = pa.tile_desc(x0, x0 + w, y0, y0 + h, 0, spp, step, phase)
+        rows = np.arange(y0 + phase, y0 + h, step)
+        idx = ((rows[:, None, None] * RES + (x0 + np.arange(w))[None, :, None]) * spp + np.arange(spp)[None, None, :]).ravel()
+        gL = L[torch.from_numpy(idx).cuda()].cpu().numpy()
+        _, oL = osc.render(cam, film, smp, integ, wt)
+        assert gL.shape == oL.shape and np.isfinite(gL).all()
+        scale = np.maximum(np.abs(oL).max(axis=-1, keepdims=True), 1e-12)
+        assert (np.abs(gL - oL) / scale).max() <= 1e-9, (x0, y0)
+    del L

@@ -142,3 +142,45 @@ def test_million_triangle_soup(ctx):
     _, Lw, (cam, film, smp, _) = _render(ctx, flat, res, 2, A.PT_INTEG_PATH, tile=wt)
     _, oL = osc.render(cam, film, smp, pa.integrator_desc(A.PT_INTEG_PATH, 5, False), wt)
     assert rel_err(Lw, oL) < RTOL
+
+
+@pytest.mark.gpu
+def test_c4_full_frame_through_two_wavefront_batches(ctx):
+    """configs[3] at its real resolution through more than one REAL wavefront batch: 1920 x 1080 x 36 spp = 74.6 M
+    paths > 2^26, so pt_render runs two batches of the default size (tests elsewhere force small batches with
+    PT_BATCH); k_trace_pair_refill and k_trace_packet on the 2 M-node tree.  Census identities, and the four row
+    bands of the frame (one batch each) add up to the two-batch frame with an equal census."""
+    import torch
+    flat = W.c4_soup(10 ** 6)
+    ctx.upload(flat)
+    res, xs = (1920, 1080), 6
+    cam, film = W.c4_camera_film(*res)
+    smp = pa.sampler_desc(0, res[0], 0, res[1], xs, xs, True, 3)
+    integ = pa.integrator_desc(A.PT_INTEG_PATH, 5, False)
+
+    def render(tiles, log=False):
+        acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
+        st = A.pt_stats()
+        batches = set()
+        for t in tiles:
+            ctx.render(cam, film, smp, integ, t, acc, stats=st)
+            if log:
+                batches |= {(r['batch'], r['kernel']) for r in ctx.launch_log() if r['stage'].startswith('trace')}
+        torch.cuda.synchronize()
+        return acc, st.as_dict(), batches
+    ctx.set_profiling(1)
+    try:
+        full, s1, batches = render([pa.tile_desc(0, res[0], 0, res[1], 0, xs * xs)], log=True)
+    finally:
+        ctx.set_profiling(0)
+    n = res[0] * res[1] * xs * xs
+    assert n > (1 << 26) and {b for b, _ in batches} == {0, 1}
+    assert {k for _, k in batches} == {'k_trace_packet', 'k_trace_pair_refill'}
+    assert s1['camera_samples'] == n and s1['rays_closest'] >= n and s1['guard_neg'] == 0 and s1['guard_inf'] > 0
+    assert s1['node_visits'] > 100 * (s1['rays_closest'] + s1['rays_any'])      # ~160 visits per ray on this tree
+    assert bool(torch.isfinite(full).all())
+    bands = [pa.tile_desc(0, res[0], (res[1] * k) // 4, (res[1] * (k + 1)) // 4, 0, xs * xs) for k in range(4)]
+    parts, s4, _ = render(bands)
+    assert s4 == s1
+    scale = float(full.abs().max())
+    assert float((parts - full).abs().max()) <= 1e-11 * scale

@@ -26,8 +26,17 @@ def test_bench_json_contract():
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert r['achieved'] > 0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 'traffic' in r
-    # the roofline is priced on the kernel alone (overlap off, after the timed region); the overlapped events are kept beside it
-    assert 'PT_OVERLAP=0' in r['measured'] and r['timed_region']['frac'] > 0 and 'traffic_source' in r
+    # top level: HIP events inside the timed region (the configuration `value` is quoted on); `exclusive`: the kernel alone
+    # (overlap off, after the timed region); per_symbol / per_launch: every traversal kernel priced by its own census
+    assert 'timed region' in r['measured'] and 'traffic_source' in r and r['avg_launch_ms'] > 0
+    x = r['exclusive']
+    assert 'PT_OVERLAP=0' in x['measured'] and x['frac'] > 0 and abs(x['frac'] - x['achieved'] / r['peak']) < 1e-12
+    assert r['per_launch'] and r['per_symbol']
+    for e in r['per_launch']:
+        assert e['symbol'].startswith('k_trace') and e['rays'] > 0 and e['ms'] > 0
+        assert abs(e['B_ray'] - (32 * e['node_visits_per_ray'] + 36 * e['tri_tests_per_ray'] + 48)) < 1e-6 * e['B_ray']
+        assert abs(e['frac'] - e['rays'] * e['B_ray'] / (e['ms'] * 1e-3) / 1e9 / r['peak']) < 1e-9
+    assert sum(v['launches'] for v in r['per_symbol'].values()) == len(r['per_launch'])
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and c['unit'] == 'Mrays/s' and c['sample']
     assert c['all_cores']['cores'] >= 1 and c['all_cores']['value'] > 0

@@ -49,17 +49,18 @@ def main():
         out.append({'launches': len(r), 'wall_us': (t1 - t0) / 1e3, 'busy_us': busy / 1e3, 'idle_us': (t1 - t0 - busy) / 1e3,
                     'per': {k: v / 1e3 for k, v in per.items()}})
     path = os.path.join(ROOT, 'profiles', tag + '_gaps.csv')
-    # group renders by launch count (full renders vs shards differ) and average
+    # group renders of one size (launch count and ray-generation time to two digits: full renders and shards differ) and average
     groups = {}
     for o in out:
-        groups.setdefault(o['launches'], []).append(o)
+        rg = o['per'].get('k_raygen', 0.)
+        groups.setdefault((o['launches'], float('%.1e' % rg)), []).append(o)
     kernels = sorted({k for o in out for k in o['per']})
     with open(path, 'w', newline='') as f:
         w = csv.writer(f)
         w.writerow(['renders', 'launches_per_render', 'wall_us', 'busy_us', 'idle_us', 'idle_pct'] + ['us ' + k for k in kernels])
         for n, g in sorted(groups.items()):
             m = lambda key: sum(o[key] for o in g) / len(g)
-            w.writerow([len(g), n, '%.1f' % m('wall_us'), '%.1f' % m('busy_us'), '%.1f' % m('idle_us'),
+            w.writerow([len(g), n[0], '%.1f' % m('wall_us'), '%.1f' % m('busy_us'), '%.1f' % m('idle_us'),
                         '%.1f' % (100. * m('idle_us') / max(m('wall_us'), 1e-9))] +
                        ['%.1f' % (sum(o['per'].get(k, 0.) for o in g) / len(g)) for k in kernels])
     print(open(path).read())
