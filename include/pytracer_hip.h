@@ -62,10 +62,18 @@ typedef enum {
 
 #define PT_MAX_LOBES 5
 #define PT_LOBE_DROP_IF_BLACK 0x10000
+/* bits 20..30 of pt_lobe.tex: k > 0 = the lobe's FLOAT parameter is texture k-1 evaluated at the hit (its first
+ * component), as the materials evaluate their float textures per hit:
+ *   PT_LOBE_OREN_NAYAR        sigma of MatteMaterial (material.py:132-139): clipped to [0, 90]; 0 makes the lobe a
+ *                             Lambertian at that hit, else a, b = A, B of OrenNayar.__init__ (orennayar.py:36-42)
+ *   PT_LOBE_MICROFACET_BLINN  roughness of Plastic / Uber (material.py:178-179, 349-350): c = min(1 / roughness, 10000)
+ * (no other lobe type may carry one) */
+#define PT_LOBE_PARAM_TEX_SHIFT 20
+#define PT_LOBE_PARAM_TEX(tex) (((tex) >> PT_LOBE_PARAM_TEX_SHIFT) & 0x7FF)
 
 typedef struct {
     int32_t type;       /* pt_lobe_type */
-    int32_t tex;        /* 0: R is the lobe's colour.  Low 16 bits k > 0: colour = R * clip(texture k-1 at the
+    int32_t tex;        /* bits 20..30: PT_LOBE_PARAM_TEX above.  Low 16 bits k > 0: colour = R * clip(texture k-1 at the
                            hit) (pt_scene_desc.textures; Material.get_bsdf evaluates its textures per hit,
                            material/material.py:131,175-176).  PT_LOBE_DROP_IF_BLACK set: the lobe exists at a
                            hit only if that colour is not black (`if not k.is_black()` of Uber / Mirror /
@@ -90,7 +98,14 @@ typedef enum {
     PT_TEX_CHECKER2D = 0,   /* Chekcerboard2DTexture :119-179, aa 'none' or 'closedform'; v[0], v[1]   */
     PT_TEX_CHECKER3D = 1,   /* Checkboard3DTexture :182-196; v[0], v[1]                                */
     PT_TEX_BILERP = 2,      /* BilerpTexture :85-104; v[0..3] = v00, v01, v10, v11                      */
-    PT_TEX_UV = 3           /* UVTexture :107-116: (s - floor s, t - floor t, 0)                        */
+    PT_TEX_UV = 3,          /* UVTexture :107-116: (s - floor s, t - floor t, 0)                        */
+    PT_TEX_WRINKLED = 4     /* WrinkledTexture :252-266 (a FLOAT texture: all three components equal):
+                               turbulence(p, 0, 0, omega, octaves) of texture/utility.py:78-101 over Perlin
+                               noise() :121-164 with the table of data/noise.py, as they execute (quirks in
+                               DESIGN.md); IdentityMapping3D only; v[0][0] = omega ("roughness"),
+                               v[0][1] = octaves (0..64), v[1][0] = the constant of a ScaleTexture(constant,
+                               WrinkledTexture) around it (:49-61), else 1.  The reference's other noise textures (FBm, Windy,
+                               Marble, Dots) raise when evaluated and are not offered                      */
 } pt_tex_kind;
 typedef enum {
     PT_MAP_UV = 0,          /* UVMapping2D texturemap:38-52; m = su, sv, du, dv                         */

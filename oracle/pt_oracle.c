@@ -130,7 +130,7 @@ int pto_scene_create(const pt_scene_desc *d, void **out) {
     for (int i = 0; i < d->n_materials; i++)
         for (int k = 0; k < s->materials[i].n_lobes; k++) {
             pt_lobe *l = &s->materials[i].lobes[k];
-            if (l->tex < 0 || (l->tex & 0xFFFF) > d->n_textures) {
+            if (l->tex < 0 || (l->tex & 0xFFFF) > d->n_textures || PT_LOBE_PARAM_TEX(l->tex) > d->n_textures) {
                 pto_scene_destroy(s);
                 return PT_ERR_ARG;
             }
@@ -320,9 +320,85 @@ static void tex_map2d(const pt_texture *t, const overtex *vx, double *s_out, dou
     }
     }
 }
+/* Perlin noise and turbulence as the reference executes them.  NOISE_PERM: pytracer/data/noise.py (Perlin's
+ * reference permutation; the reference stores it twice over, 512 entries, so that x + 1 = 256 needs no wrap —
+ * reducing every index modulo 256 is the same look-up). */
+static const unsigned char NOISE_PERM[256] = {
+    151, 160, 137,  91,  90,  15, 131,  13, 201,  95,  96,  53, 194, 233,   7, 225,
+    140,  36, 103,  30,  69, 142,   8,  99,  37, 240,  21,  10,  23, 190,   6, 148,
+    247, 120, 234,  75,   0,  26, 197,  62,  94, 252, 219, 203, 117,  35,  11,  32,
+     57, 177,  33,  88, 237, 149,  56,  87, 174,  20, 125, 136, 171, 168,  68, 175,
+     74, 165,  71, 134, 139,  48,  27, 166,  77, 146, 158, 231,  83, 111, 229, 122,
+     60, 211, 133, 230, 220, 105,  92,  41,  55,  46, 245,  40, 244, 102, 143,  54,
+     65,  25,  63, 161,   1, 216,  80,  73, 209,  76, 132, 187, 208,  89,  18, 169,
+    200, 196, 135, 130, 116, 188, 159,  86, 164, 100, 109, 198, 173, 186,   3,  64,
+     52, 217, 226, 250, 124, 123,   5, 202,  38, 147, 118, 126, 255,  82,  85, 212,
+    207, 206,  59, 227,  47,  16,  58,  17, 182, 189,  28,  42, 223, 183, 170, 213,
+    119, 248, 152,   2,  44, 154, 163,  70, 221, 153, 101, 155, 167,  43, 172,   9,
+    129,  22,  39, 253,  19,  98, 108, 110,  79, 113, 224, 232, 178, 185, 112, 104,
+    218, 246,  97, 228, 251,  34, 242, 193, 238, 210, 144,  12, 191, 179, 162, 241,
+     81,  51, 145, 235, 249,  14, 239, 107,  49, 192, 214,  31, 181, 199, 106, 157,
+    184,  84, 204, 176, 115, 121,  50,  45, 127,   4, 150, 254, 138, 236, 205,  93,
+    222, 114,  67,  29,  24,  72, 243, 141, 128, 195,  78,  66, 215,  61, 156, 180,
+};
+/* _grad, texture/utility.py:104-114.  `if h & 1: u = -1` assigns the constant -1 (pbrt negates u). */
+static double noise_grad(int x, int y, int z, double dx, double dy, double dz) {
+    int h = NOISE_PERM[(NOISE_PERM[(NOISE_PERM[x & 255] + y) & 255] + z) & 255];
+    h &= 15;
+    double u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+    double v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+    if (h & 1) u = -1.;
+    if (h & 2) v = -v;
+    return u + v;
+}
+static inline double olerp(double t, double v1, double v2) { return (1. - t) * v1 + t * v2; }   /* util.lerp, utility.py:89-91 */
+/* noise(), texture/utility.py:121-164.  y1 is interpolated with wz (pbrt uses wy). */
+static double perlin_noise(v3 p) {
+    double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    double dx = p.x - fx, dy = p.y - fy, dz = p.z - fz;
+    int xi = (int)((long long)fx & 255), yi = (int)((long long)fy & 255), zi = (int)((long long)fz & 255);
+    double w000 = noise_grad(xi, yi, zi, dx, dy, dz);
+    double w100 = noise_grad(xi + 1, yi, zi, dx - 1, dy, dz);
+    double w010 = noise_grad(xi, yi + 1, zi, dx, dy - 1, dz);
+    double w110 = noise_grad(xi + 1, yi + 1, zi, dx - 1, dy - 1, dz);
+    double w001 = noise_grad(xi, yi, zi + 1, dx, dy, dz - 1);
+    double w101 = noise_grad(xi + 1, yi, zi + 1, dx - 1, dy, dz - 1);
+    double w011 = noise_grad(xi, yi + 1, zi + 1, dx, dy - 1, dz - 1);
+    double w111 = noise_grad(xi + 1, yi + 1, zi + 1, dx - 1, dy - 1, dz - 1);
+    double wx = dx * dx * dx * (10. - 15. * dx + 6. * dx * dx);
+    double wy = dy * dy * dy * (10. - 15. * dy + 6. * dy * dy);
+    double wz = dz * dz * dz * (10. - 15. * dz + 6. * dz * dz);
+    double x00 = olerp(wx, w000, w100), x10 = olerp(wx, w010, w110);
+    double x01 = olerp(wx, w001, w101), x11 = olerp(wx, w011, w111);
+    double y0 = olerp(wy, x00, x10), y1 = olerp(wz, x01, x11);
+    return olerp(wz, y0, y1);
+}
+/* turbulence(), texture/utility.py:78-101, with the zero differentials every material look-up has (material.py:128
+ * dg_s.copy(), diffgeom.py:40-42): s2 = 0, np.log2(0) = -inf, foct = min(max_octaves, inf) = max_octaves.
+ * smooth_step (:43-50) clips its argument INTO [lo, hi] instead of normalising it. */
+static double turbulence(v3 p, double omega, double max_octaves) {
+    double foct = max_octaves, fo = floor(foct);
+    int octaves = fo > 64. ? 64 : (fo > 0. ? (int)fo : 0);
+    double s = 0., l = 1., o = 1.;
+    for (int i = 0; i < octaves; i++) {
+        s += o * fabs(perlin_noise(vmul(p, l)));
+        l *= 1.99;
+        o *= omega;
+    }
+    double par = foct - fo;
+    double v = par < .3 ? .3 : (par > .7 ? .7 : par);
+    s += o * (v * v * (3. - 2. * v)) * fabs(perlin_noise(vmul(p, l)));
+    return s;
+}
+
 static v3 tex_eval(const pt_texture *t, const overtex *vx) {
     double s = 0., tt = 0.;
     switch (t->kind) {
+    case PT_TEX_WRINKLED: {    /* WrinkledTexture.__call__, texture/__init__.py:262-266 */
+        /* v[1][0]: the constant of a ScaleTexture(constant, WrinkledTexture) (texture/__init__.py:49-61), else 1 */
+        double w = t->v[1][0] * turbulence(xform_point(t->m, vx->p), t->v[0][0], t->v[0][1]);
+        return V(w, w, w);
+    }
     case PT_TEX_CHECKER2D:     /* :147-152 / :162-166 */
         tex_map2d(t, vx, &s, &tt);
         return ((((long long)floor(s) + (long long)floor(tt)) & 1) == 0) ? V(t->v[0][0], t->v[0][1], t->v[0][2])
@@ -361,6 +437,25 @@ static void apply_textures(const oscene *sc, overtex *vx) {
             l.R[0] *= c.x; l.R[1] *= c.y; l.R[2] *= c.z;
             /* `if not k.is_black()`: the lobe is not pushed at this hit (spectrum.py:182-187) */
             if ((l.tex & PT_LOBE_DROP_IF_BLACK) && l.R[0] < PT_EPS && l.R[1] < PT_EPS && l.R[2] < PT_EPS) continue;
+        }
+        const int pi = PT_LOBE_PARAM_TEX(l.tex);
+        if (pi) {   /* a float texture as the lobe's parameter */
+            double f = tex_eval(sc->textures + (pi - 1), vx).x;
+            if (l.type == PT_LOBE_OREN_NAYAR) {
+                /* MatteMaterial.get_bsdf, material.py:132-139 + OrenNayar.__init__, orennayar.py:36-42 */
+                double sigma = f < 0. ? 0. : (f > 90. ? 90. : f);
+                if (sigma == 0.) { l.type = PT_LOBE_LAMBERT; l.a = 0.; l.b = 0.; }
+                else {
+                    double sig = sigma * (M_PI / 180.);
+                    double sig_sq = sig * sig;
+                    l.a = 1. - (sig_sq / (2. * (sig_sq + 0.33)));
+                    l.b = .45 * sig_sq / (sig_sq + .09);
+                }
+            } else {
+                /* Plastic / Uber: Blinn(1. / rough), material.py:178-179,349-350; exponent clipped, torrance.py:66-67 */
+                double e = 1. / f;
+                l.c = e > 10000. ? 10000. : e;
+            }
         }
         l.tex = 0;
         vx->tmat.lobes[n++] = l;
@@ -1354,6 +1449,20 @@ int pto_hit_geometry(void *scene, const double *ray8, int32_t prim, double t, do
 }
 
 /* light.sample_l: out[18] = Li, wi, pdf, shadow o, d, mint, maxt */
+/* One texture at one point: out[3] = tex_eval (textures 0-based; p = the shading point, (u, v) its surface
+ * coordinates).  For tests that compare with the reference's Texture.__call__. */
+int pto_texture_eval(void *scene, int32_t tex, const double *p, double u, double v, double *out) {
+    const oscene *s = (const oscene *)scene;
+    if (!s || tex < 0 || tex >= s->n_textures) return PT_ERR_ARG;
+    overtex vx;
+    memset(&vx, 0, sizeof(vx));
+    vx.p = V(p[0], p[1], p[2]);
+    vx.u = u; vx.v = v;
+    v3 c = tex_eval(s->textures + tex, &vx);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
+    return PT_OK;
+}
+
 int pto_sample_l(void *scene, int32_t light, const double *p, double pEps, double u1, double u2, double *out) {
     const oscene *s = (const oscene *)scene;
     olsample ls;

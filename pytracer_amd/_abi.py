@@ -11,7 +11,8 @@ PT_OK, PT_ERR_ARG, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_DEPTH, PT_ERR_CAPACITY = 
  PT_LOBE_MICROFACET_BLINN_COND, PT_LOBE_MEASURED_IRISO) = range(7)
 PT_LIGHT_DIFFUSE_SPHERE, PT_LIGHT_SPOT, PT_LIGHT_POINT = range(3)
 PT_LOBE_DROP_IF_BLACK = 0x10000
-PT_TEX_CHECKER2D, PT_TEX_CHECKER3D, PT_TEX_BILERP, PT_TEX_UV = range(4)
+PT_TEX_CHECKER2D, PT_TEX_CHECKER3D, PT_TEX_BILERP, PT_TEX_UV, PT_TEX_WRINKLED = range(5)
+PT_LOBE_PARAM_TEX_SHIFT = 20
 PT_MAP_UV, PT_MAP_PLANAR, PT_MAP_SPHERICAL, PT_MAP_IDENTITY3D = range(4)
 PT_INTEG_DIRECT, PT_INTEG_PATH, PT_INTEG_WHITTED = 0, 1, 2
 PT_CAM_PERSPECTIVE, PT_CAM_ORTHO = 0, 1

@@ -550,10 +550,11 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
         (d->n_lights && !d->lights) || d->n_textures < 0 || (d->n_textures && !d->textures))
         return fail(c, PT_ERR_ARG, "null array");
     for (int i = 0; i < d->n_textures; i++)
-        if (d->textures[i].kind < 0 || d->textures[i].kind > PT_TEX_UV || d->textures[i].mapping < 0 ||
+        if (d->textures[i].kind < 0 || d->textures[i].kind > PT_TEX_WRINKLED || d->textures[i].mapping < 0 ||
             d->textures[i].mapping > PT_MAP_IDENTITY3D ||
-            ((d->textures[i].kind == PT_TEX_CHECKER3D) != (d->textures[i].mapping == PT_MAP_IDENTITY3D)))
-            return fail(c, PT_ERR_ARG, "texture %d: kind / mapping", i);
+            ((d->textures[i].kind == PT_TEX_CHECKER3D || d->textures[i].kind == PT_TEX_WRINKLED) != (d->textures[i].mapping == PT_MAP_IDENTITY3D)) ||
+            (d->textures[i].kind == PT_TEX_WRINKLED && !(d->textures[i].v[0][1] >= 0. && d->textures[i].v[0][1] <= 64.)))
+            return fail(c, PT_ERR_ARG, "texture %d: kind / mapping / octaves", i);
     if (d->n_lights > 16) return fail(c, PT_ERR_CAPACITY, "at most 16 lights");
     DeviceGuard dg(c->device);
     HIPCHK(c, dg.err);
@@ -575,7 +576,10 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
                     (b > 0. && (!d->brdf_p || !d->brdf_v)) || b > 1e9)
                     return fail(c, PT_ERR_ARG, "material %d: measured BRDF sample range", i);
             }
-            if (m.lobes[k].tex < 0 || (m.lobes[k].tex & 0xFFFF) > d->n_textures || (m.lobes[k].tex & ~(0xFFFF | PT_LOBE_DROP_IF_BLACK))) return fail(c, PT_ERR_ARG, "material %d: texture index", i);
+            if (m.lobes[k].tex < 0 || (m.lobes[k].tex & 0xFFFF) > d->n_textures || PT_LOBE_PARAM_TEX(m.lobes[k].tex) > d->n_textures ||
+                (m.lobes[k].tex & ~(0xFFFF | PT_LOBE_DROP_IF_BLACK | (0x7FF << PT_LOBE_PARAM_TEX_SHIFT))) ||
+                (PT_LOBE_PARAM_TEX(m.lobes[k].tex) && m.lobes[k].type != PT_LOBE_OREN_NAYAR && m.lobes[k].type != PT_LOBE_MICROFACET_BLINN))
+                return fail(c, PT_ERR_ARG, "material %d: texture index", i);
             spec |= m.lobes[k].type == PT_LOBE_SPEC_REFLECT;
         }
     }

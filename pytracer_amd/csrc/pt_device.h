@@ -266,9 +266,82 @@ __device__ inline void tex_map2d(const pt_texture &t, d3 p, double u, double v, 
         t_out = ph * PT_INV_2PI;
     }
 }
+// Perlin's reference permutation (Improved Noise, 2002), the table of pytracer/data/noise.py (there doubled to 512
+// entries; indices are reduced modulo 256 here, which is the same look-up).
+__device__ const unsigned char PT_NOISE_PERM[256] = {
+    151, 160, 137,  91,  90,  15, 131,  13, 201,  95,  96,  53, 194, 233,   7, 225,
+    140,  36, 103,  30,  69, 142,   8,  99,  37, 240,  21,  10,  23, 190,   6, 148,
+    247, 120, 234,  75,   0,  26, 197,  62,  94, 252, 219, 203, 117,  35,  11,  32,
+     57, 177,  33,  88, 237, 149,  56,  87, 174,  20, 125, 136, 171, 168,  68, 175,
+     74, 165,  71, 134, 139,  48,  27, 166,  77, 146, 158, 231,  83, 111, 229, 122,
+     60, 211, 133, 230, 220, 105,  92,  41,  55,  46, 245,  40, 244, 102, 143,  54,
+     65,  25,  63, 161,   1, 216,  80,  73, 209,  76, 132, 187, 208,  89,  18, 169,
+    200, 196, 135, 130, 116, 188, 159,  86, 164, 100, 109, 198, 173, 186,   3,  64,
+     52, 217, 226, 250, 124, 123,   5, 202,  38, 147, 118, 126, 255,  82,  85, 212,
+    207, 206,  59, 227,  47,  16,  58,  17, 182, 189,  28,  42, 223, 183, 170, 213,
+    119, 248, 152,   2,  44, 154, 163,  70, 221, 153, 101, 155, 167,  43, 172,   9,
+    129,  22,  39, 253,  19,  98, 108, 110,  79, 113, 224, 232, 178, 185, 112, 104,
+    218, 246,  97, 228, 251,  34, 242, 193, 238, 210, 144,  12, 191, 179, 162, 241,
+     81,  51, 145, 235, 249,  14, 239, 107,  49, 192, 214,  31, 181, 199, 106, 157,
+    184,  84, 204, 176, 115, 121,  50,  45, 127,   4, 150, 254, 138, 236, 205,  93,
+    222, 114,  67,  29,  24,  72, 243, 141, 128, 195,  78,  66, 215,  61, 156, 180,
+};
+// _grad AS WRITTEN, texture/utility.py:104-114: `if h & 1: u = -1` sets u to the constant -1 (not -u)
+__device__ __forceinline__ double noise_grad(int x, int y, int z, double dx, double dy, double dz) {
+    int h = PT_NOISE_PERM[(PT_NOISE_PERM[(PT_NOISE_PERM[x & 255] + y) & 255] + z) & 255];
+    h &= 15;
+    double u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+    double v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+    if (h & 1) u = -1.;
+    if (h & 2) v = -v;
+    return u + v;
+}
+__device__ __forceinline__ double pt_lerp(double t, double v1, double v2) { return (1. - t) * v1 + t * v2; }   // util.lerp
+// noise() AS WRITTEN, texture/utility.py:121-164 (y1 is interpolated with wz, not wy)
+__device__ inline double perlin_noise(double px, double py, double pz) {
+    const double fx = floor(px), fy = floor(py), fz = floor(pz);
+    const double dx = px - fx, dy = py - fy, dz = pz - fz;
+    // util.ftoi then `& (NOISE_PERM_SIZE - 1)` on a Python int: the low 8 bits of the two's complement
+    const int xi = (int)((long long)fx & 255), yi = (int)((long long)fy & 255), zi = (int)((long long)fz & 255);
+    const double w000 = noise_grad(xi, yi, zi, dx, dy, dz), w100 = noise_grad(xi + 1, yi, zi, dx - 1, dy, dz);
+    const double w010 = noise_grad(xi, yi + 1, zi, dx, dy - 1, dz), w110 = noise_grad(xi + 1, yi + 1, zi, dx - 1, dy - 1, dz);
+    const double w001 = noise_grad(xi, yi, zi + 1, dx, dy, dz - 1), w101 = noise_grad(xi + 1, yi, zi + 1, dx - 1, dy, dz - 1);
+    const double w011 = noise_grad(xi, yi + 1, zi + 1, dx, dy - 1, dz - 1);
+    const double w111 = noise_grad(xi + 1, yi + 1, zi + 1, dx - 1, dy - 1, dz - 1);
+    const double wx = dx * dx * dx * (10. - 15. * dx + 6. * dx * dx);
+    const double wy = dy * dy * dy * (10. - 15. * dy + 6. * dy * dy);
+    const double wz = dz * dz * dz * (10. - 15. * dz + 6. * dz * dz);
+    const double x00 = pt_lerp(wx, w000, w100), x10 = pt_lerp(wx, w010, w110);
+    const double x01 = pt_lerp(wx, w001, w101), x11 = pt_lerp(wx, w011, w111);
+    const double y0 = pt_lerp(wy, x00, x10), y1 = pt_lerp(wz, x01, x11);
+    return pt_lerp(wz, y0, y1);
+}
+// turbulence() AS IT EXECUTES for a material's texture look-up, texture/utility.py:78-101: the differentials are zero
+// (Q16), so s2 = 0, log2(0) = -inf and foct = min(max_octaves, +inf) = max_octaves; smooth_step(.3, .7, par) clips par
+// INTO [.3, .7] (utility.py:43-50), so the partial octave always contributes (weight .216 when par = 0).
+__device__ inline double turbulence(d3 p, double omega, double max_octaves) {
+    const double foct = max_octaves;
+    const double fo = floor(foct);
+    const int octaves = fo > 64. ? 64 : (fo > 0. ? (int)fo : 0);      // range(octaves); PT_TEX_WRINKLED allows at most 64
+    double sum = 0., l = 1., o = 1.;
+    for (int i = 0; i < octaves; i++) {
+        sum += o * fabs(perlin_noise(l * p.x, l * p.y, l * p.z));
+        l *= 1.99;
+        o *= omega;
+    }
+    const double par = foct - fo;
+    const double v = par < .3 ? .3 : (par > .7 ? .7 : par);
+    sum += o * (v * v * (3. - 2. * v)) * fabs(perlin_noise(l * p.x, l * p.y, l * p.z));
+    return sum;
+}
+
 __device__ inline d3 tex_eval(const pt_texture &t, d3 p, double u, double v) {
     double s = 0., tt = 0.;
     switch (t.kind) {
+    case PT_TEX_WRINKLED: {                        // WrinkledTexture, texture/__init__.py:252-266
+        const double w = t.v[1][0] * turbulence(xform_point(t.m, p), t.v[0][0], t.v[0][1]);   // v[1][0]: a ScaleTexture's constant, else 1
+        return mk3(w, w, w);
+    }
     case PT_TEX_CHECKER2D:                         // :147-152 / :162-166
         tex_map2d(t, p, u, v, s, tt);
         return ((((long long)floor(s) + (long long)floor(tt)) & 1) == 0) ? mk3(t.v[0][0], t.v[0][1], t.v[0][2])
@@ -316,6 +389,27 @@ __device__ inline void apply_textures(const DScene &sc, Vertex &vx, int prim, do
             l.R[0] *= max0(c.x); l.R[1] *= max0(c.y); l.R[2] *= max0(c.z);
             // `if not k.is_black()` (material.py:217-219,289-295,343-362): the lobe is not pushed at this hit
             if ((l.tex & PT_LOBE_DROP_IF_BLACK) && l.R[0] < PT_EPS && l.R[1] < PT_EPS && l.R[2] < PT_EPS) continue;
+        }
+        const int pi = PT_LOBE_PARAM_TEX(l.tex);
+        if (pi) {
+            // the lobe's float parameter from a FLOAT texture, per hit
+            const double f = tex_eval(sc.textures[pi - 1], vx.p, u, v).x;
+            if (l.type == PT_LOBE_OREN_NAYAR) {
+                // MatteMaterial, material.py:132-139: sigma = np.clip(self.sigma(dgs), 0., 90.); Lambertian when it is 0,
+                // else OrenNayar.__init__ (orennayar.py:36-42)
+                const double sigma = f < 0. ? 0. : (f > 90. ? 90. : f);      // NaN stays NaN, as in np.clip
+                if (sigma == 0.) { l.type = PT_LOBE_LAMBERT; l.a = 0.; l.b = 0.; }
+                else {
+                    const double sig = sigma * (PT_PI / 180.);               // np.deg2rad
+                    const double sig_sq = sig * sig;
+                    l.a = 1. - (sig_sq / (2. * (sig_sq + 0.33)));
+                    l.b = .45 * sig_sq / (sig_sq + .09);
+                }
+            } else {
+                // Plastic / Uber, material.py:178-179,349-350: Blinn(1. / rough); Blinn.__init__ clips at 10000 (torrance.py:66-67)
+                const double e = 1. / f;
+                l.c = e > 10000. ? 10000. : e;
+            }
         }
         l.tex = 0;
         scratch->lobes[n++] = l;

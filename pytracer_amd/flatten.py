@@ -12,7 +12,10 @@ Materials are evaluated at flatten time into the ordered lobe list ``Material.ge
 ConstantTextures (or Scale/Mix of constants, folded here); the spectrum parameters whose lobe is pushed
 of Matte (Kd), Plastic (Kd, Ks), Uber (Kd, Ks, Kr, Kt), Mirror (Kr) and Glass (Kr, Kt) may also be a
 checkerboard / bilerp / UV texture (``texture_record``), evaluated per hit on the device — including the
-``is_black`` tests with which Uber / Mirror / Glass decide per hit whether a lobe exists.
+``is_black`` tests with which Uber / Mirror / Glass decide per hit whether a lobe exists.  The FLOAT parameters
+sigma of Matte and roughness of Plastic / Uber may be a float texture as well (``WrinkledTexture`` — the one noise
+texture the reference can evaluate — or a checkerboard / bilerp of float constants): the lobe then carries a
+parameter texture (``PT_LOBE_PARAM_TEX``) and the device derives A, B / the Blinn exponent per hit.
 """
 import ctypes as C
 
@@ -46,6 +49,15 @@ def _blinn_exponent(rough):
     return float(np.clip(1. / rough, -np.inf, 10000.))
 
 
+def _with_param(ex, ptex):
+    """the lobe's extras tuple with a parameter-texture record merged in"""
+    if ptex is None:
+        return ex
+    d = dict(ex[0]) if ex else {}
+    d['ptex'] = ptex
+    return (d,)
+
+
 def _colour(v, scale=None, drop=False):
     """(R, extras, exists) of a spectrum parameter.  A constant is clipped (and scaled) here and `exists` is the
     material's own is_black test when `drop`.  A texture record (dict, see texture_record) leaves R = scale (or 1)
@@ -67,14 +79,17 @@ def lobes_from_params(kind, **p):
     measured lobe with {'brdf': (p[n,3], v[n,3])})
     """
     out = []
-    textured_ok = {'matte': ('Kd',), 'plastic': ('Kd', 'Ks'), 'uber': ('Kd', 'Ks', 'Kr', 'Kt'), 'mirror': ('Kr',),
-                   'glass': ('Kr', 'Kt')}
+    textured_ok = {'matte': ('Kd', 'sigma'), 'plastic': ('Kd', 'Ks', 'roughness'),
+                   'uber': ('Kd', 'Ks', 'Kr', 'Kt', 'roughness'), 'mirror': ('Kr',), 'glass': ('Kr', 'Kt')}
     for name, v in p.items():
         if isinstance(v, dict) and name not in textured_ok.get(kind, ()):
             raise NotImplementedError('a non-constant texture is supported for the colours %s of %s only, not for %s'
                                       % ('/'.join(textured_ok.get(kind, ())) or '(none)', kind, name))
     if kind == 'matte':                         # material.py:122-141
         r, ex, _ = _colour(p['Kd'])
+        if isinstance(p['sigma'], dict):        # a float texture: Lambertian or Oren-Nayar, and A, B, decided per hit
+            out.append((A.PT_LOBE_OREN_NAYAR, r, 0., 0., 0.) + _with_param(ex, p['sigma']))
+            return out
         sigma = float(np.clip(p['sigma'], 0., 90.))
         if sigma == 0.:
             out.append((A.PT_LOBE_LAMBERT, r, 0., 0., 0.) + ex)
@@ -94,7 +109,10 @@ def lobes_from_params(kind, **p):
             out.append((A.PT_LOBE_LAMBERT, kd, 0., 0., 0.) + ex)
         ks, ex, on = _colour(p['Ks'], op, True)
         if on:
-            out.append((A.PT_LOBE_MICROFACET_BLINN, ks, e, 1., _blinn_exponent(float(p['roughness']))) + ex)
+            if isinstance(p['roughness'], dict):
+                out.append((A.PT_LOBE_MICROFACET_BLINN, ks, e, 1., 0.) + _with_param(ex, p['roughness']))
+            else:
+                out.append((A.PT_LOBE_MICROFACET_BLINN, ks, e, 1., _blinn_exponent(float(p['roughness']))) + ex)
         kr, ex, on = _colour(p['Kr'], op, True)
         if on:
             out.append((A.PT_LOBE_SPEC_REFLECT, kr, e, 1., 0.) + ex)
@@ -105,7 +123,10 @@ def lobes_from_params(kind, **p):
         kd, exd, _ = _colour(p['Kd'])
         ks, exs, _ = _colour(p['Ks'])
         out.append((A.PT_LOBE_LAMBERT, kd, 0., 0., 0.) + exd)
-        out.append((A.PT_LOBE_MICROFACET_BLINN, ks, 1.5, 1., _blinn_exponent(float(p['roughness']))) + exs)
+        if isinstance(p['roughness'], dict):
+            out.append((A.PT_LOBE_MICROFACET_BLINN, ks, 1.5, 1., 0.) + _with_param(exs, p['roughness']))
+        else:
+            out.append((A.PT_LOBE_MICROFACET_BLINN, ks, 1.5, 1., _blinn_exponent(float(p['roughness']))) + exs)
     elif kind == 'mirror':                      # material.py:208-222
         r, ex, on = _colour(p['Kr'], None, True)
         if on:
@@ -168,10 +189,11 @@ def _mapping_record(mp):
     raise NotImplementedError('texture mapping %s is outside the supported hot path' % nm)
 
 
-def texture_record(t):
-    """{'kind', 'mapping', 'm'[16], 'v'[4][3]} of a spectrum texture over constant children
-    (include/pytracer_hip.h pt_texture).  Children are clipped here: util.clip of the selected child
-    (material.py:131) is the selection of the clipped children."""
+def texture_record(t, clip=True):
+    """{'kind', 'mapping', 'm'[16], 'v'[4][3]} of a texture over constant children (include/pytracer_hip.h
+    pt_texture).  Spectrum textures (clip=True): children are clipped here — util.clip of the selected child
+    (material.py:131) is the selection of the clipped children.  Float textures (clip=False: sigma, roughness) are
+    not clipped by the materials; a float child c is stored as (c, c, c) and the device reads the first component."""
     nm = type(t).__name__
     v = np.zeros((4, 3))
 
@@ -179,7 +201,31 @@ def texture_record(t):
         c = _const(x)
         if c is None:
             raise NotImplementedError('textures nested in %s must be constant' % nm)
-        return _clip(_spec(c))
+        if not clip and np.ndim(c) != 0:
+            raise NotImplementedError('a float parameter needs a float texture: %s has a spectrum child' % nm)
+        return _clip(_spec(c)) if clip else _spec(c)
+    scale = 1.
+    if not clip and nm == 'ScaleTexture':       # ScaleTexture(constant, WrinkledTexture): tex1(dg) * tex2(dg), :49-61
+        kids = [t.tex1, t.tex2]
+        consts = [_const(k) for k in kids]
+        var = [k for k, c in zip(kids, consts) if c is None]
+        if len(var) != 1 or type(var[0]).__name__ != 'WrinkledTexture' or np.ndim([c for c in consts if c is not None][0]) != 0:
+            raise NotImplementedError('a varying ScaleTexture must be a float constant times a WrinkledTexture')
+        scale = float([c for c in consts if c is not None][0])
+        t = var[0]
+        nm = type(t).__name__
+    if not clip and nm in ('BilerpTexture', 'UVTexture'):
+        raise NotImplementedError('%s is a spectrum texture: not usable as a float parameter' % nm)
+    if nm == 'WrinkledTexture':                 # texture/__init__.py:252-266: turbulence over Perlin noise, a float
+        if clip:
+            raise NotImplementedError('WrinkledTexture is a float texture: sigma / roughness, not a colour')
+        mk, m = _mapping_record(t.mapping)
+        if mk != A.PT_MAP_IDENTITY3D:
+            raise NotImplementedError('WrinkledTexture needs a 3D mapping')
+        if not 0. <= float(t.octaves) <= 64.:
+            raise NotImplementedError('WrinkledTexture with %r octaves' % (t.octaves,))
+        v[0, 0], v[0, 1], v[1, 0] = float(t.omega), float(t.octaves), scale
+        return dict(kind=int(A.PT_TEX_WRINKLED), mapping=int(mk), m=m, v=v)
     if nm == 'Chekcerboard2DTexture':
         kind = A.PT_TEX_CHECKER2D           # 'closedform' == 'none': materials zero the differentials
         v[0], v[1] = child(t.tex1), child(t.tex2)
@@ -199,13 +245,16 @@ def texture_record(t):
     return dict(kind=int(kind), mapping=int(mk), m=m, v=v)
 
 
-def _tex(t, spectrum=False):
-    """Evaluate a surface-constant texture; with spectrum=True a supported varying texture gives its record."""
+def _tex(t, spectrum=False, float_tex=False):
+    """Evaluate a surface-constant texture; with spectrum=True (float_tex=True) a supported varying spectrum (float)
+    texture gives its record."""
     c = _const(t)
     if c is not None:
         return c
     if spectrum:
         return texture_record(t)
+    if float_tex:
+        return texture_record(t, clip=False)
     raise NotImplementedError('only constant textures are supported for this parameter, got %s' % type(t).__name__)
 
 
@@ -215,12 +264,12 @@ def material_params(mat):
     if getattr(mat, 'bump_map', None) is not None:
         raise NotImplementedError('bump mapping is outside the supported hot path')
     if nm == 'MatteMaterial':
-        return 'matte', dict(Kd=_tex(mat.Kd, True), sigma=_tex(mat.sigma))
+        return 'matte', dict(Kd=_tex(mat.Kd, True), sigma=_tex(mat.sigma, float_tex=True))
     if nm == 'UberMaterial':
         return 'uber', dict(Kd=_tex(mat.Kd, True), Ks=_tex(mat.Ks, True), Kr=_tex(mat.Kr, True), Kt=_tex(mat.Kt, True),
-                            roughness=_tex(mat.roughness), opacity=_tex(mat.opacity), eta=_tex(mat.eta))
+                            roughness=_tex(mat.roughness, float_tex=True), opacity=_tex(mat.opacity), eta=_tex(mat.eta))
     if nm == 'PlasticMaterial':
-        return 'plastic', dict(Kd=_tex(mat.Kd, True), Ks=_tex(mat.Ks, True), roughness=_tex(mat.roughness))
+        return 'plastic', dict(Kd=_tex(mat.Kd, True), Ks=_tex(mat.Ks, True), roughness=_tex(mat.roughness, float_tex=True))
     if nm == 'MirrorMaterial':
         return 'mirror', dict(Kr=_tex(mat.Kr, True))
     if nm == 'GlassMaterial':
@@ -268,8 +317,14 @@ def _pack_material(lobes, textures=None, brdfs=None):
         elif extras is not None:
             if textures is None:
                 raise ValueError('textured lobe without a texture table')
-            textures.append(extras['tex'])
-            m.lobes[i].tex = len(textures) | (A.PT_LOBE_DROP_IF_BLACK if extras.get('drop') else 0)
+            if 'tex' in extras:
+                textures.append(extras['tex'])
+                m.lobes[i].tex = len(textures) | (A.PT_LOBE_DROP_IF_BLACK if extras.get('drop') else 0)
+            if 'ptex' in extras:                  # the lobe's float parameter (PT_LOBE_PARAM_TEX)
+                textures.append(extras['ptex'])
+                if len(textures) > 0x7FF:
+                    raise ValueError('more than 2047 textures before a parameter texture')
+                m.lobes[i].tex |= len(textures) << A.PT_LOBE_PARAM_TEX_SHIFT
     return m
 
 

@@ -43,6 +43,7 @@ def lib():
         L.pto_camera_rays.argtypes = [C.POINTER(A.pt_camera), C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
         L.pto_hit_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
                                        C.c_void_p]
+        L.pto_texture_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.pto_sample_l.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.pto_lobe_eval.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                     C.c_void_p]
@@ -104,6 +105,14 @@ class OracleScene(object):
         a, b = np.ascontiguousarray(wo, np.float64), np.ascontiguousarray(wi, np.float64)
         rc = lib().pto_lobe_eval(self._h, int(mat), int(lobe), a.ctypes.data, b.ctypes.data, float(u1), float(u2),
                                  out.ctypes.data)
+        assert rc == 0, rc
+        return out
+
+    def texture_eval(self, tex, p, u=0., v=0.):
+        """texture `tex` (0-based index into the scene's texture records) at shading point p, surface coordinates (u, v)"""
+        p = np.ascontiguousarray(p, np.float64)
+        out = np.zeros(3)
+        rc = lib().pto_texture_eval(self._h, int(tex), p.ctypes.data, float(u), float(v), out.ctypes.data)
         assert rc == 0, rc
         return out
 

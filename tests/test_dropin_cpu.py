@@ -127,7 +127,8 @@ sys.path.insert(0, %r); sys.path.insert(0, %r)
 import gen_fixtures as G
 assert 'pytracer_amd' not in sys.modules, 'the fixture generator imports the product'
 dumps = {}
-for variant, fname in (('tex', 'texmini_path_24x24x4.npz'), ('tex2', 'tex2mini_path_24x24x4.npz'), ('uv', 'uvmini_path_24x24x4.npz')):
+for variant, fname in (('tex', 'texmini_path_24x24x4.npz'), ('tex2', 'tex2mini_path_24x24x4.npz'), ('uv', 'uvmini_path_24x24x4.npz'),
+                       ('wrink', 'wrinkmini_path_24x24x4.npz')):
     model = G.C4Mini(variant)
     d = G.dump_scene(model.scene)
     assert 'pytracer_amd' not in sys.modules
@@ -148,6 +149,14 @@ for variant, model in dumps.items():
                 continue
             a, b = G.texture_dump(t), F.texture_record(t)
             assert a['kind'] == b['kind'] and a['mapping'] == b['mapping']
+            assert np.array_equal(a['m'], b['m']) and np.array_equal(a['v'], b['v'])
+            n += 1
+        for name in ('sigma', 'roughness'):        # float parameters: WrinkledTexture, alone or under a ScaleTexture
+            t = getattr(pr.material, name, None)
+            if t is None or G.is_surface_constant(t):
+                continue
+            a, b = G.texture_dump(t, is_float=True), F.texture_record(t, clip=False)
+            assert a['kind'] == b['kind'] == 4 and a['mapping'] == b['mapping']
             assert np.array_equal(a['m'], b['m']) and np.array_equal(a['v'], b['v'])
             n += 1
 assert n > 0

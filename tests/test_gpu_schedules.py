@@ -34,7 +34,7 @@ SCENES = [('head_path_32x32x4.npz', A.PT_INTEG_PATH), ('head_direct_24x24x4.npz'
           ('c4mini_path_24x24x4.npz', A.PT_INTEG_PATH), ('tex2mini_whitted_24x24x1.npz', A.PT_INTEG_WHITTED),
           ('specmini_path_24x24x4.npz', A.PT_INTEG_PATH), ('c4mini_direct_24x24x1.npz', A.PT_INTEG_DIRECT),
           ('measmini_path_24x24x4.npz', A.PT_INTEG_PATH), ('tex2mini_path_24x24x4.npz', A.PT_INTEG_PATH),
-          ('uvmini_path_24x24x4.npz', A.PT_INTEG_DIRECT)]
+          ('uvmini_path_24x24x4.npz', A.PT_INTEG_DIRECT), ('wrinkmini_path_24x24x4.npz', A.PT_INTEG_PATH)]
 
 
 def render(torch, env, flat, d, kind, win, spp, seed):

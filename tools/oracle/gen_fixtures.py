@@ -74,7 +74,7 @@ def tex_value(t):
 
 # Texture / mapping codes of include/pytracer_hip.h (pt_texture.kind / .mapping), restated here so that the fixture
 # INPUTS do not pass through the product's flattener (tests/test_dropin_cpu.py compares the two on live objects).
-TEX_KIND = {'Chekcerboard2DTexture': 0, 'Checkboard3DTexture': 1, 'BilerpTexture': 2, 'UVTexture': 3}
+TEX_KIND = {'Chekcerboard2DTexture': 0, 'Checkboard3DTexture': 1, 'BilerpTexture': 2, 'UVTexture': 3, 'WrinkledTexture': 4}
 MAP_KIND = {'UVMapping2D': 0, 'PlannarMapping2D': 1, 'SphericalMapping2D': 2, 'IdentityMapping3D': 3}
 SURFACE_CONSTANT = ('ConstantTexture', 'ScaleTexture', 'MixTexture')
 
@@ -94,17 +94,32 @@ def as_rgb(v):
     return np.full(3, float(v)) if v.ndim == 0 else np.array(v, np.float64)
 
 
-def texture_dump(t):
-    """{'kind', 'mapping', 'm'[16], 'v'[4][3]} of a spatially varying spectrum texture, read off the reference object:
+def texture_dump(t, is_float=False):
+    """{'kind', 'mapping', 'm'[16], 'v'[4][3]} of a spatially varying texture, read off the reference object:
     the values of constant children are the REFERENCE's own evaluation (t(None)), clipped as the materials clip what
-    they evaluate (material.py:131); the mapping's 16 doubles are its attributes in the order pt_texture documents."""
+    they evaluate (material.py:131; float parameters — sigma, roughness — are not clipped there and not here);
+    the mapping's 16 doubles are its attributes in the order pt_texture documents."""
     nm = type(t).__name__
     v = np.zeros((4, 3))
+    scale = 1.
+    if is_float and nm == 'ScaleTexture':      # ScaleTexture(constant, WrinkledTexture): tex1(dg) * tex2(dg)
+        kids = [t.tex1, t.tex2]
+        const = [k for k in kids if is_surface_constant(k)]
+        var = [k for k in kids if not is_surface_constant(k)]
+        assert len(const) == 1 and len(var) == 1 and type(var[0]).__name__ == 'WrinkledTexture'
+        scale = float(const[0](None))
+        t = var[0]
+        nm = type(t).__name__
 
     def child(x):
         assert is_surface_constant(x), 'children of %s must be constant over the surface' % nm
+        if is_float:
+            return as_rgb(float(x(None)))
         return np.clip(as_rgb(x(None)), 0., np.inf)
-    if nm in ('Chekcerboard2DTexture', 'Checkboard3DTexture'):
+    if nm == 'WrinkledTexture':
+        assert is_float
+        v[0, 0], v[0, 1], v[1, 0] = float(t.omega), float(t.octaves), scale
+    elif nm in ('Chekcerboard2DTexture', 'Checkboard3DTexture'):
         v[0], v[1] = child(t.tex1), child(t.tex2)
     elif nm == 'BilerpTexture':
         for k, c in enumerate((t.v00, t.v01, t.v10, t.v11)):
@@ -133,6 +148,14 @@ def spec_param(t):
     if is_surface_constant(t):
         return np.array(t(None))
     return texture_dump(t)
+
+
+def float_param(t):
+    """A float parameter (sigma, roughness): the reference's own value of a constant texture, or the record of a
+    varying float texture."""
+    if is_surface_constant(t):
+        return float(t(None))
+    return texture_dump(t, is_float=True)
 
 
 def dump_scene(scene, camera=None):
@@ -179,11 +202,11 @@ def dump_scene(scene, camera=None):
     for mt in mats:
         nm = type(mt).__name__
         if nm == 'MatteMaterial':
-            mrec.append(dict(kind=0, Kd=spec_param(mt.Kd), sigma=float(mt.sigma(None))))
+            mrec.append(dict(kind=0, Kd=spec_param(mt.Kd), sigma=float_param(mt.sigma)))
         elif nm == 'UberMaterial':
             mrec.append(dict(kind=1, Kd=spec_param(mt.Kd), Ks=spec_param(mt.Ks),
                              Kr=spec_param(mt.Kr), Kt=spec_param(mt.Kt),
-                             roughness=float(mt.roughness(None)), opacity=np.array(mt.opacity(None)),
+                             roughness=float_param(mt.roughness), opacity=np.array(mt.opacity(None)),
                              eta=float(mt.eta(None))))
         elif nm == 'MetalMaterial':
             mrec.append(dict(kind=5, eta=np.array(mt.eta(None)), k=np.array(mt.k(None)),
@@ -194,7 +217,7 @@ def dump_scene(scene, camera=None):
             mrec.append(dict(kind=4, Kr=spec_param(mt.Kr), Kt=spec_param(mt.Kt), index=float(mt.index(None))))
         elif nm == 'PlasticMaterial':
             mrec.append(dict(kind=2, Kd=spec_param(mt.Kd), Ks=spec_param(mt.Ks),
-                             roughness=float(mt.roughness(None))))
+                             roughness=float_param(mt.roughness)))
         elif nm == 'MeasuredMaterial':
             mrec.append(dict(kind=6, brdf_p=np.array([np.array(x.p) for x in mt.theta_phi_samples]),
                              brdf_v=np.array([np.array(x.v) for x in mt.theta_phi_samples])))
@@ -621,6 +644,22 @@ class C4Mini(object):
                                  c3([0., 0., 0.]), ConstantTexture(.2), c3([.8, .8, .8]), ConstantTexture(1.33)),
                     MatteMaterial(c3([.5, .5, .5]), ConstantTexture(0.))]
             nmesh = 3
+        if variant == 'wrink':
+            # the one noise texture the reference can evaluate (FBm / Windy / Marble raise UnboundLocalError, Dots
+            # TypeError): WrinkledTexture, a FLOAT texture, as Matte sigma and as Plastic / Uber roughness
+            from pytracer.texture.texture import WrinkledTexture, ScaleTexture, Chekcerboard2DTexture
+            from pytracer.texture.texturemap import IdentityMapping3D, UVMapping2D
+            c3 = lambda v: ConstantTexture(Spectrum(v))
+            self.wrinkled = [WrinkledTexture(3, .5, IdentityMapping3D(Transform.scale(.7, .9, 1.1))),
+                             WrinkledTexture(4, .6, IdentityMapping3D(Transform.translate(geo.Vector(3.3, -1.7, .4)))),
+                             WrinkledTexture(2, .45, IdentityMapping3D(Transform.scale(1.7, 1.7, 1.7)))]
+            mats = [MatteMaterial(c3([.6, .3, .2]), ScaleTexture(ConstantTexture(40.), self.wrinkled[0])),
+                    PlasticMaterial(Chekcerboard2DTexture(UVMapping2D(4., 4., 0., 0.), c3([.2, .4, .6]), c3([.5, .2, .2])),
+                                    c3([.3, .3, .3]), ScaleTexture(self.wrinkled[1], ConstantTexture(.2))),
+                    UberMaterial(c3([.3, .2, .2]), c3([.25, .25, .25]), c3([0., 0., 0.]), c3([0., 0., 0.]),
+                                 self.wrinkled[2], c3([1., 1., 1.]), ConstantTexture(1.33)),
+                    MatteMaterial(c3([.5, .5, .5]), self.wrinkled[0])]
+            nmesh = 3
         if variant == 'spec':
             # specular chains: a mirror, glass, and an Uber material with a specular-reflection component
             c3 = lambda v: ConstantTexture(Spectrum(v))
@@ -674,7 +713,7 @@ class C4Mini(object):
         lights = [SpotLight(spot_l2w, Spectrum(200.), 30., 25.),
                   PointLight(Transform.translate(geo.Vector(8., -6., -12.)), Spectrum(150.)),
                   DiffuseAreaLight(st, Spectrum(10.), 2, sph)]
-        if variant in ('spec', 'xtra', 'tex', 'tex2', 'uv', 'meas'):
+        if variant in ('spec', 'xtra', 'tex', 'tex2', 'uv', 'meas', 'wrink'):
             lights = lights[1:]
         self.scene = Scene(BVH(prims), lights, None)
 
@@ -1016,6 +1055,41 @@ def gen_tex2():
 
 
 ALL['tex2'] = gen_tex2
+
+
+def gen_wrink():
+    """WrinkledTexture (texture/texture/__init__.py:252-266) as Matte sigma and Plastic / Uber roughness under
+    Direct, Path and Whitted, plus the reference's own values of the three textures at 400 points."""
+    model = C4Mini('wrink')
+    cam = model.configure_camera(x_res=24, y_res=24, file_name='/tmp/_fixture.png')
+    sc = dump_scene(model.scene, cam)
+    rng = np.random.default_rng(77)
+    pts = np.concatenate([rng.uniform(-12., 12., (300, 3)), rng.uniform(-300., 300., (60, 3)),
+                          np.round(rng.uniform(-5., 5., (40, 3)))])        # lattice points: noise() = 0 there
+    from pytracer.geometry.diffgeom import DifferentialGeometry
+
+    class _DG(object):
+        pass
+    vals = np.zeros((len(model.wrinkled), len(pts)))
+    for k, tex in enumerate(model.wrinkled):
+        for i, p in enumerate(pts):
+            dg = _DG()
+            dg.p, dg.dpdx, dg.dpdy = geo.Point(*p), geo.Vector(0., 0., 0.), geo.Vector(0., 0., 0.)
+            vals[k, i] = float(tex(dg))
+    sc['wr_points'], sc['wr_values'] = pts, vals
+    sc['wr_records_m'] = np.array([np.array(t.mapping.w2t.m, np.float64).ravel() for t in model.wrinkled])
+    sc['wr_records_oo'] = np.array([[float(t.omega), float(t.octaves)] for t in model.wrinkled])
+    for name, integ, xs in (('direct', DirectLightingIntegrator(), 1), ('path', PathIntegrator(max_depth=5), 2),
+                            ('whitted', WhittedIntegrator(), 1)):
+        t = time.time()
+        d = instrumented_render(model, 24, 24, xs, xs, integ, seed=61)
+        d.update(sc)
+        np.savez_compressed(os.path.join(OUT, 'wrinkmini_%s_24x24x%d.npz' % (name, xs * xs)), **d)
+        print('wrinkmini %s: %.1fs, rays logged %d, sumL %.6f, zero-L %d of %d' % (
+            name, time.time() - t, len(d['log_rays']), d['L'].sum(), int((d['L'].sum(1) == 0).sum()), len(d['L'])), flush=True)
+
+
+ALL['wrink'] = gen_wrink
 
 
 def gen_uv():
