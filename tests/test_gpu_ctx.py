@@ -95,3 +95,55 @@ def test_two_contexts_on_one_device_render_concurrently(golden_dir):
     assert float(accs[0].abs().sum()) > 0 and float(accs[1].abs().sum()) > 0
     for c in ctxs:
         c.close()
+
+
+def test_one_process_drives_eight_contexts(golden_dir):
+    """The other multi-GPU shape the ABI allows (include/pytracer_hip.h: "one Python process drives 8 ctxs"): ONE process,
+    one context per rank, every context rendering its interleaved-row shard of the same job into its OWN full-frame film
+    on its own stream, all in flight together, the films summed at the end (what `dist.reduce` does across processes).
+    Here the eight contexts share the one GPU of the box: the sum equals the one-context film (1e-12: the order of the f64
+    atomic adds is free), the summed census equals the one-context census, and no context disturbs another's state."""
+    import torch
+    from pytracer_amd import host
+    from pytracer_amd._lib import Context
+    from pytracer_amd.renderer import shard_tile
+    flat = pa.flat_scene_from_npz(dict(np.load(os.path.join(golden_dir, 'head_mesh_scene.npz'))))
+    R, K = 256, 8
+    cam, film = host.head_mesh_camera_film(R, R)
+    smp = pa.sampler_desc(0, R, 0, R, 4, 4, True, 9)
+    integ = pa.integrator_desc(A.PT_INTEG_PATH, 5, False)
+    one = Context(0)
+    one.upload(flat)
+    whole = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
+    s1 = A.pt_stats()
+    one.render(cam, film, smp, integ, pa.tile_desc(0, R, 0, R, 0, 16), whole, stats=s1)
+    torch.cuda.synchronize()
+    one.close()
+    ctxs = [Context(0) for _ in range(K)]
+    try:
+        for c in ctxs:
+            c.upload(flat)
+        streams = [torch.cuda.Stream() for _ in range(K)]
+        films = [torch.zeros_like(whole) for _ in range(K)]
+        torch.cuda.synchronize()
+        for rep in range(2):                       # the second round re-uses every context's workspace while others run
+            for f in films:
+                f.zero_()
+            torch.cuda.synchronize()
+            for r in range(K):                     # stats=None: nothing synchronises, all eight renders are queued at once
+                ctxs[r].render(cam, film, smp, integ, shard_tile(smp, r, K, 'interleaved'), films[r],
+                               stream=streams[r].cuda_stream)
+            torch.cuda.synchronize()
+            total = torch.stack(films).sum(0)
+            assert float((total - whole).abs().max()) <= 1e-12 * float(whole.abs().max())
+        # the census, shard by shard (a synchronising call each), adds up to the one-context census
+        sk = A.pt_stats()
+        for r in range(K):
+            films[r].zero_()
+            ctxs[r].render(cam, film, smp, integ, shard_tile(smp, r, K, 'interleaved'), films[r], stats=sk,
+                           stream=streams[r].cuda_stream)
+        torch.cuda.synchronize()
+        assert sk.as_dict() == s1.as_dict()
+    finally:
+        for c in ctxs:
+            c.close()
