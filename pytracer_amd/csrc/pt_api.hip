@@ -221,7 +221,16 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     c->shade_dynamic = -1;
     if (const char *e = getenv("PT_SHADE_DYNAMIC")) c->shade_dynamic = atoi(e);
     if (const char *e = getenv("PT_TRACE_DYNAMIC")) c->trace_dynamic = atoi(e);
-    CREATE_CHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    {
+        // the second stream carries the any-hit traces, which nothing but the final splat waits for: PT_AUX_PRIORITY=1
+        // creates it with the lowest priority so that the critical path on the caller's stream is served first
+        int lo = 0, hi = 0, prio = 0;
+        if (const char *e = getenv("PT_AUX_PRIORITY")) prio = atoi(e);
+        if (prio != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            CREATE_CHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio > 0 ? lo : hi));
+        else
+            CREATE_CHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    }
     for (int k = 0; k < 2; k++) {
         CREATE_CHK(hipEventCreateWithFlags(&c->ev_shade[k], hipEventDisableTiming));
         CREATE_CHK(hipEventCreateWithFlags(&c->ev_any[k], hipEventDisableTiming));
