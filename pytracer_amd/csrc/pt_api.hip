@@ -36,6 +36,8 @@ struct pt_ctx {
     DScene sc;
     void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf, *d_tri_cls, *d_frames;
     void *d_meta;            // packed (offset, n_prim | axis) words of all nodes (DScene::node_meta)
+    void *d_pairs_h;         // GPairH records (the same at half size)
+    int pair_half;           // PT_PAIR_HALF: k_trace_pair_refill reads the half-size records; unset (-1) = yes
     void *d_pairs;           // GPair records of the interior nodes (k_trace_pair)
     int n_pairs;
     int use_pair;            // PT_TRACE_PAIR: 0 never, 1 always, unset (-1) = by tree size (launch_trace)
@@ -80,7 +82,7 @@ struct pt_ctx {
     int *d_counts;           // [6][PT_CNT_BLOCK]: region counter blocks of q0, q1, shadow queue 0, the hit list of even
                              // levels, shadow queue 1, the hit list of odd levels
     int trace_occ[2];        // resident blocks/CU of the closest / any trace kernels (0 = not queried)
-    int pair_occ[2];         // the same for k_trace_pair
+    int pair_occ[2][2];      // the same for k_trace_pair / the half-record k_trace_pair_refill, [half][any]
     int pair_levels;         // todo levels the tree needs; the first pair_lds_levels of them live in LDS (PT_PAIR_LDS_LEVELS)
     int pair_lds_levels;
     long pair_max_blocks;    // grid limit of k_trace_pair = what d_spill was sized for (a multiple of PT_SEG_BLOCKS)
@@ -210,6 +212,8 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     if (const char *e = getenv("PT_TRACE_PACKET")) c->use_packet = atoi(e);
     if (const char *e = getenv("PT_PAIR_REFILL")) c->pair_refill = atoi(e);
     if (const char *e = getenv("PT_REFILL_MIN")) c->refill_min = atoi(e);
+    c->pair_half = -1;
+    if (const char *e = getenv("PT_PAIR_HALF")) c->pair_half = atoi(e);
     c->sort_rays = -1;
     if (const char *e = getenv("PT_SORT_RAYS")) c->sort_rays = atoi(e);
     c->sort_window = 4096;
@@ -338,7 +342,7 @@ extern "C" int pt_launch_log(pt_ctx *c, pt_launch_record *out, int32_t cap, int3
 
 static void free_scene(pt_ctx *c) {
     void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top,
-                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill, &c->d_tri_cls, &c->d_frames, &c->d_meta};
+                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill, &c->d_tri_cls, &c->d_frames, &c->d_meta, &c->d_pairs_h};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -666,6 +670,35 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
         c->n_pairs = n_pairs;
         if (n_pairs > 0) {
             HIPCHK(c, upload(&c->d_pairs, pairs.data(), pairs.size()));
+            {   // the same records with binary32 outer boxes
+                std::vector<GPairH> ph((size_t)n_pairs);
+                float w_max = 0.f;
+                for (size_t k = 0; k < ph.size(); k++) {
+                    const GPair &p = pairs[k];
+                    GPairH &h = ph[k];
+                    double w = 0.;
+                    for (int ch = 0; ch < 2; ch++) {
+                        const double *b = ch ? p.b1 : p.b0;
+                        float *o = ch ? h.b1 : h.b0;
+                        for (int a = 0; a < 6; a++) {
+                            float f = (float)b[a];
+                            if (a < 3) { if ((double)f > b[a]) f = nextafterf(f, -INFINITY); }     // minima towards -inf
+                            else { if ((double)f < b[a]) f = nextafterf(f, INFINITY); }            // maxima towards +inf
+                            o[a] = f;
+                            const double dist = fabs((double)f - b[a]);
+                            w = (dist > w || dist != dist) ? dist : w;
+                        }
+                    }
+                    float wf = (float)w;
+                    if ((double)wf < w) wf = nextafterf(wf, INFINITY);
+                    if (!(w == w)) wf = INFINITY;                                                 // NaN box: always the exact record
+                    h.w = wf;
+                    w_max = wf > w_max ? wf : w_max;
+                    h.ref0 = p.ref0; h.ref1 = p.ref1; h.axis = p.axis;
+                }
+                c->sc.pair_w_max = w_max;
+                HIPCHK(c, upload(&c->d_pairs_h, ph.data(), ph.size()));
+            }
             // todo stacks: <= one entry per level of the tree (+ margin); the first L levels in LDS, all of them again
             // in the spill area (the literal walk of rays with zero / NaN direction components uses only that)
             c->pair_levels = (std::max(depth, 1) + 2) & ~1;
@@ -777,6 +810,7 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     s.nodes = (const GNode *)c->d_nodes;
     s.node_meta = (const int2 *)c->d_meta;
     s.pairs = (const GPair *)c->d_pairs;
+    s.pairs_h = (const GPairH *)c->d_pairs_h;
     s.top = n_top ? (const TopNode *)c->d_top : nullptr;
     s.n_top = n_top;
     s.exact_slab = exact_slab_scene ? 1 : 0;
@@ -803,7 +837,7 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     }
     c->stack_need = std::max(depth, 1);
     c->trace_occ[0] = c->trace_occ[1] = 0;
-    c->pair_occ[0] = c->pair_occ[1] = 0;
+    memset(c->pair_occ, 0, sizeof(c->pair_occ));
     c->has_spec_reflect = spec;
     c->shadow_per_vertex_direct = spv;
     c->have_scene = true;
@@ -867,9 +901,13 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
     int use_pair = c->use_pair;
     if (use_pair < 0) use_pair = c->meta_stack > 0 ? 0 : 3;
     if (c->d_pairs && c->n_pairs > 0 && c->d_spill && (use_pair & (any ? 2 : 1))) {
-        int &occ = c->pair_occ[any ? 1 : 0];
+        // lane refill (k_trace_pair_refill) pays where walks are long and uneven: by tree size unless PT_PAIR_REFILL says;
+        // it reads the half-size records unless PT_PAIR_HALF=0 (soup, 16 spp, one stream: closest 59.5 -> 55.5 ms, any 30.7 -> 27.3)
+        const bool refill = seg_counts && (n_val & PT_TRACE_DYNAMIC) && (c->pair_refill < 0 ? c->sc.n_nodes >= (1 << 20) : c->pair_refill != 0);
+        const bool half = refill && c->pair_half != 0;
+        int &occ = c->pair_occ[half ? 1 : 0][any ? 1 : 0];
         if (occ == 0) {
-            occ = pt_trace_pair_occupancy(any, c->pair_lds_levels);
+            occ = pt_trace_pair_occupancy(any, c->pair_lds_levels, half);
             // the occupancy API counts LDS to the byte; a grid one block per CU too large leaves a partial second
             // residency round (measured: 32 KB stacks, API 5, 117 vs 88 ms): keep a margin
             const long by_lds = ((long)160 * 1024 - 4096) / (long)std::max<size_t>(pt_trace_pair_lds(c->pair_lds_levels), 1);
@@ -881,12 +919,10 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
         long grid = std::max<long>(1, std::min<long>(blocks, (long)c->n_cu * per_cu));
         if (seg_counts) grid = ((grid + PT_SEG_BLOCKS - 1) / PT_SEG_BLOCKS) * PT_SEG_BLOCKS;   // whole sets of PT_SEG waves
         grid = std::min<long>(grid, c->pair_max_blocks);                                        // what the spill area holds
-        // lane refill (k_trace_pair_refill) pays where walks are long and uneven: by tree size unless PT_PAIR_REFILL says
-        const bool refill = c->pair_refill < 0 ? c->sc.n_nodes >= (1 << 20) : c->pair_refill != 0;
         char *spill = (char *)c->d_spill + (any ? pt_trace_pair_spill_bytes(c->pair_levels, c->pair_max_blocks * 256) : 0);
-        *kid = (seg_counts && refill && (n_val & PT_TRACE_DYNAMIC)) ? PT_KERNEL_TRACE_PAIR_REFILL : PT_KERNEL_TRACE_PAIR;
+        *kid = refill ? PT_KERNEL_TRACE_PAIR_REFILL : PT_KERNEL_TRACE_PAIR;
         return pt_launch_trace_pair(any, c->pair_lds_levels, spill, (int)grid, stream, c->sc, rays, stride, seg_counts,
-                                    seg, (seg_counts && refill) ? (n_val | PT_TRACE_REFILL) : n_val, out_prim, out_t, out_b1, out_b2, rs, counters,
+                                    seg, refill ? (n_val | PT_TRACE_REFILL | (half ? PT_TRACE_HALF : 0)) : n_val, out_prim, out_t, out_b1, out_b2, rs, counters,
                                     c->refill_min, order);
     }
     // ... for launches that can hold enough rays to pay for its 1024-thread workgroups and their LDS staging: a launch

@@ -109,6 +109,20 @@ struct __attribute__((aligned(128))) GPair {
 };
 static_assert(sizeof(GPair) == 128, "one cache line");
 
+// The same record at half the size (k_trace_pair_refill_h): the child boxes as binary32 OUTER boxes (minima rounded towards
+// -inf, maxima towards +inf) and `w`, an upper bound of the distance any of the twelve planes moved.  The walk decides a
+// box test on the outer box when it can prove that the reference's binary64 test on the exact box gives the same answer
+// (a missed outer box is a missed box; a hit whose margins exceed what w can change is a hit) and fetches the exact GPair
+// otherwise — so results and census stay bit-identical while a step moves 64 bytes instead of 128.
+struct __attribute__((aligned(64))) GPairH {
+    float b0[6];         // first child: bmin xyz (rounded down), bmax xyz (rounded up)
+    float b1[6];         // second child
+    int32_t ref0, ref1;  // as in GPair
+    int32_t axis;
+    float w;             // >= |outer plane - exact plane| for all twelve planes (rounded up; inf: always fetch the exact record)
+};
+static_assert(sizeof(GPairH) == 64, "half a cache line");
+
 // Top-of-tree record staged in LDS by k_trace_top (pt_kernels.hip): a GNode whose padding holds
 // the references of its two children.  ref >= 0: index into DScene::nodes; ref < 0: LDS slot ~ref.
 struct __attribute__((aligned(16))) TopNode {   // 64 B
@@ -137,6 +151,8 @@ struct BrdfGrid {
 struct DScene {
     const GNode *nodes;
     const GPair *pairs;        // one record per interior node, numbered in depth-first order (root = 0), (k_tri_frames at upload)
+    const GPairH *pairs_h;     // the same records with binary32 outer boxes (nullptr: not built)
+    float pair_w_max;          // the largest GPairH::w of the scene
     const TopNode *top;        // the first n_top nodes in breadth-first order, (k_tri_frames at upload)
     int32_t n_top;
     int32_t exact_slab;        // a node box with min > max (or NaN): only the reference's own comparison order is exact

@@ -59,6 +59,7 @@ __host__ __device__ inline int pt_tile_row_y(const pt_tile &t, int row) {
 #define PT_CNT_CURSOR 1
 #define PT_TRACE_DYNAMIC 1
 #define PT_TRACE_PACKET 4    // with PT_TRACE_DYNAMIC: a launch over coherent chunks (level 0 of a render) walks per wave (k_trace_packet)
+#define PT_TRACE_HALF 8      // with PT_TRACE_REFILL: the pair records are read at half size (GPairH: binary32 outer boxes, exact fallback)
 #define PT_TRACE_REFILL 2    // with PT_TRACE_DYNAMIC, k_trace_pair launches: lanes that finish take new rays (k_trace_pair_refill)
 #define PT_SEG_BLOCKS (PT_SEG / (PT_BLOCK / 64))
 
@@ -166,7 +167,7 @@ size_t pt_trace_top_lds(int stack, int n_top);
 // k_trace_pair: the walk fetched by parent (GPair records); `stack` todo levels of 8-byte entries in LDS
 size_t pt_trace_pair_lds(int lds_levels);
 size_t pt_trace_pair_spill_bytes(int levels, long grid_threads);
-int pt_trace_pair_occupancy(bool any, int lds_levels);
+int pt_trace_pair_occupancy(bool any, int lds_levels, bool half);   // half: of the half-record refill kernel
 // grid must already be a whole number of PT_SEG-wave sets for segmented input (the caller sized `spill` for it)
 hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid, hipStream_t stream, const DScene &sc,
                                 const double *rays, long stride, const int *seg_counts, long seg, int n_val, int *out_prim,

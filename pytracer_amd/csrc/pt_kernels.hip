@@ -722,6 +722,152 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair(DSc
     if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
 }
 
+// ---- half-size pair records --------------------------------------------------------------------------------------------
+// pair_step with the child boxes read from GPairH (binary32 outer boxes, 64 bytes).  For each child the reference's test
+// (the fast slab form on the exact binary64 box) is
+//     ok = (tnear <= tfar) && (tnear < maxt) && (tfar > mint),   tnear / tfar = max / min over the axes of the plane distances
+//     t = fl(fl(b - o) * inv).
+// The same expressions on the OUTER box give tnear_o <= tnear and tfar_o >= tfar (rounding is monotone), so a missed outer
+// box is a missed box.  Every plane distance moves by at most
+//     (w + 2^-48 |b_o - o|) |inv|        (w >= |b_o - b|; the second term covers the roundings of both evaluations)
+// which is at most E = w A + R with two numbers per RAY: A = max |inv| over the axes, R = 2^-48 max (S_a |inv_a|),
+// S_a = |o_a| + the largest |coordinate| of the root box on axis a (every box lies inside the root box); both carry a factor
+// 1 + 2^-40, R an absolute 2^-1000.  The exact test is a hit whenever
+//     tnear_o + E <= tfar_o - E,  tnear_o + E < maxt,  tfar_o - E > mint.
+// Anything in between (a ray within a binary32 ulp of grazing the box, or of the current maxt) fetches the exact GPair and
+// runs the exact test for both children.  The far child's stack entry keeps the high word of tnear_o - E, a lower bound of
+// the exact tnear; at the pop the exact value lies between the smaller double with that high word and the larger one
+// + 2 E_max (E_max = w_max A + R with the largest w of the scene): `tnear < maxt` is settled unless maxt falls in that
+// interval, and then exact_tnear_lt_maxt re-tests on the exact box.
+struct HalfBound { double A, R; };
+__device__ __forceinline__ HalfBound half_bound(const DScene &sc, const Ray &r, const SlabRay &sv) {
+    const GNode &root = sc.nodes[0];
+    const double aix = fabs(sv.invx), aiy = fabs(sv.invy), aiz = fabs(sv.invz);
+    const double sx = fabs(r.o.x) + fmax(fabs(root.bmin[0]), fabs(root.bmax[0]));
+    const double sy = fabs(r.o.y) + fmax(fabs(root.bmin[1]), fabs(root.bmax[1]));
+    const double sz = fabs(r.o.z) + fmax(fabs(root.bmin[2]), fabs(root.bmax[2]));
+    HalfBound h;
+    h.A = fmax(fmax(aix, aiy), aiz) * 1.0000000000009095;                                        // 1 + 2^-40
+    h.R = 3.552713678800501e-15 * fmax(fmax(sx * aix, sy * aiy), sz * aiz) * 1.0000000000009095 + 9.332636185032189e-302;
+    return h;
+}
+template <bool ANY, int BLOCK>
+__device__ __forceinline__ bool pair_step_h(const DScene &sc, Ray &r, const SlabRay &sv, const HalfBound &hb, const PairStack &stack,
+                                            int &ref, int &todo, unsigned &pend, int &result, double &b1o, double &b2o,
+                                            unsigned &nvis, unsigned &ntri) {
+    int next;
+    if (ref < 0) {
+        const int first = ~ref;
+        int n = 1;
+        for (int i = 0; i < n; i++) {
+            const double2 *q = reinterpret_cast<const double2 *>(sc.tris + first + i);
+            const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+            if (i == 0) n = __double2loint(a4.y);          // GTri::leaf_nprim
+            double t, b1, b2;
+            ntri++;
+            if (tri_math(a0, a1, a2, a3, a4, r, t, b1, b2)) {
+                if (ANY) { result = 1; return true; }
+                result = first + i;
+                b1o = b1; b2o = b2;
+                r.maxt = t;
+            }
+        }
+        next = PT_PAIR_POP;
+    } else {
+        const float4 *q = reinterpret_cast<const float4 *>(sc.pairs_h + ref);
+        const float4 f0 = q[0], f1 = q[1], f2 = q[2];
+        const int4 m = *reinterpret_cast<const int4 *>(&q[3]);         // ref0, ref1, axis, w
+        // b0 = f0.x f0.y f0.z | f0.w f1.x f1.y     b1 = f1.z f1.w f2.x | f2.y f2.z f2.w
+        const double ax0 = ((double)f0.x - r.o.x) * sv.invx, ax1 = ((double)f0.w - r.o.x) * sv.invx;
+        const double ay0 = ((double)f0.y - r.o.y) * sv.invy, ay1 = ((double)f1.x - r.o.y) * sv.invy;
+        const double az0 = ((double)f0.z - r.o.z) * sv.invz, az1 = ((double)f1.y - r.o.z) * sv.invz;
+        const double bx0 = ((double)f1.z - r.o.x) * sv.invx, bx1 = ((double)f2.y - r.o.x) * sv.invx;
+        const double by0 = ((double)f1.w - r.o.y) * sv.invy, by1 = ((double)f2.z - r.o.y) * sv.invy;
+        const double bz0 = ((double)f2.x - r.o.z) * sv.invz, bz1 = ((double)f2.w - r.o.z) * sv.invz;
+        double tn0 = fmax(fmax(fmin(ax0, ax1), fmin(ay0, ay1)), fmin(az0, az1));
+        const double tf0 = fmin(fmin(fmax(ax0, ax1), fmax(ay0, ay1)), fmax(az0, az1));
+        double tn1 = fmax(fmax(fmin(bx0, bx1), fmin(by0, by1)), fmin(bz0, bz1));
+        const double tf1 = fmin(fmin(fmax(bx0, bx1), fmax(by0, by1)), fmax(bz0, bz1));
+        bool ok0 = (tn0 <= tf0) && (tn0 < r.maxt) && (tf0 > r.mint);
+        bool ok1 = (tn1 <= tf1) && (tn1 < r.maxt) && (tf1 > r.mint);
+        double eb = 0.;
+        if (ok0 || ok1) {       // an outer box was hit: is the exact box hit too?
+            eb = (double)__int_as_float(m.w) * hb.A + hb.R;
+            const bool sure0 = (tn0 + eb <= tf0 - eb) && (tn0 + eb < r.maxt) && (tf0 - eb > r.mint);
+            const bool sure1 = (tn1 + eb <= tf1 - eb) && (tn1 + eb < r.maxt) && (tf1 - eb > r.mint);
+            if ((ok0 && !sure0) || (ok1 && !sure1)) {
+                // too close to call on the outer boxes: the exact record, the exact test (as pair_step)
+                const double2 *x = reinterpret_cast<const double2 *>(sc.pairs + ref);
+                const double2 c0 = x[0], c1 = x[1], c2 = x[2], d0 = x[3], d1 = x[4], d2 = x[5];
+                const double xa0 = (c0.x - r.o.x) * sv.invx, xa1 = (c1.y - r.o.x) * sv.invx;
+                const double ya0 = (c0.y - r.o.y) * sv.invy, ya1 = (c2.x - r.o.y) * sv.invy;
+                const double za0 = (c1.x - r.o.z) * sv.invz, za1 = (c2.y - r.o.z) * sv.invz;
+                const double xb0 = (d0.x - r.o.x) * sv.invx, xb1 = (d1.y - r.o.x) * sv.invx;
+                const double yb0 = (d0.y - r.o.y) * sv.invy, yb1 = (d2.x - r.o.y) * sv.invy;
+                const double zb0 = (d1.x - r.o.z) * sv.invz, zb1 = (d2.y - r.o.z) * sv.invz;
+                tn0 = fmax(fmax(fmin(xa0, xa1), fmin(ya0, ya1)), fmin(za0, za1));
+                const double xf0 = fmin(fmin(fmax(xa0, xa1), fmax(ya0, ya1)), fmax(za0, za1));
+                tn1 = fmax(fmax(fmin(xb0, xb1), fmin(yb0, yb1)), fmin(zb0, zb1));
+                const double xf1 = fmin(fmin(fmax(xb0, xb1), fmax(yb0, yb1)), fmax(zb0, zb1));
+                ok0 = (tn0 <= xf0) && (tn0 < r.maxt) && (xf0 > r.mint);
+                ok1 = (tn1 <= xf1) && (tn1 < r.maxt) && (xf1 > r.mint);
+                eb = 0.;
+            }
+        }
+        const bool neg = (sv.negmask >> m.z) & 1;                       // near child = second child when negative
+        const bool okN = neg ? ok1 : ok0, okF = neg ? ok0 : ok1;
+        const int refN = neg ? m.y : m.x, refF = neg ? m.x : m.y;
+        nvis++;                                                         // the near child's visit
+        if (okN) {
+            if (okF) {
+                PairEnt e;
+                e.ref = refF;
+                if (ANY) e.aux = (int)pend;
+                else {
+                    // the high word of a LOWER bound of the exact tnear; the pop adds the ray's largest possible 2 E on top
+                    e.aux = __double2hiint((neg ? tn0 : tn1) - eb);
+                }
+                pair_push<BLOCK>(stack, todo, e);
+                todo++;
+                pend = 0;
+            } else if (ANY) pend++;
+            else nvis++;                                                // closest: it will be popped and missed
+            next = refN;
+        } else {
+            nvis++;                                                     // the far child is popped right away
+            next = okF ? refF : PT_PAIR_POP;
+        }
+    }
+    if (next == PT_PAIR_POP) {
+        if (ANY) {
+            nvis += pend;
+            if (todo == 0) return true;
+            todo--;
+            const PairEnt e = pair_pop<BLOCK>(stack, todo);
+            nvis++;
+            pend = (unsigned)e.aux;
+            next = e.ref;
+        } else {
+            for (;;) {
+                if (todo == 0) return true;
+                todo--;
+                const PairEnt e = pair_pop<BLOCK>(stack, todo);
+                nvis++;
+                // exact tnear in [the smaller of the two doubles with this high word, the larger one + 2 E], E <= w_max A + R
+                const double lo = __hiloint2double(e.aux, 0), hi = __hiloint2double(e.aux, (int)0xFFFFFFFF);
+                const double e2 = 2. * ((double)sc.pair_w_max * hb.A + hb.R);
+                const bool sure_hit = (r.maxt > lo + e2) && (r.maxt > hi + e2);
+                const bool sure_miss = (r.maxt <= lo) && (r.maxt <= hi);
+                bool hit = sure_hit;
+                if (!sure_hit && !sure_miss) hit = exact_tnear_lt_maxt(sc, e.ref, r, sv.invx, sv.invy, sv.invz);
+                if (hit) { next = e.ref; break; }
+            }
+        }
+    }
+    ref = next;
+    return false;
+}
+
 // k_trace_pair_refill: the same walk with the wave's lanes kept busy.  A chunk of 64 rays ends with its longest ray: on
 // the 10^6-triangle soup the lanes of k_trace_pair are busy 31 % of a wave's steps (sum of visits / 64 x longest
 // lane, measured), and that walk is bound by the latency of its fetches, not by their number — an idle lane is a
@@ -735,8 +881,15 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair(DSc
 #ifndef PT_REFILL_MIN
 #define PT_REFILL_MIN 32
 #endif
-template <bool ANY>
-__global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair_refill(
+// waves per SIMD of the half-record kernels, measured on the 10^6-triangle soup (16 spp, one stream): closest-hit 4
+// (109 VGPRs, no scratch: 55.5 ms; 5 -> 96 VGPRs + 48 B scratch: 57.3; 6 -> 86.8), any-hit 5 (27.3 ms; 4 -> 29.0; 6 -> 32.4)
+#ifndef PT_PAIRH_WAVES
+#define PT_PAIRH_WAVES(ANY) ((ANY) ? 5 : 4)
+#endif
+// HALF: the pair records are read at half size (GPairH, pair_step_h above).  SORT: rays are taken through `order`
+// (k_sort_rays); a template argument because the pointer costs the default kernels 16-40 bytes of scratch.
+template <bool ANY, bool HALF, bool SORT>
+__global__ __launch_bounds__(PT_PAIR_BLOCK, HALF ? PT_PAIRH_WAVES(ANY) : PT_PAIR_WAVES) void k_trace_pair_refill(
     DScene sc, const double *__restrict__ rays, long stride, const int *__restrict__ seg_counts, long seg,
     int *__restrict__ out_prim, double *__restrict__ out_t, double *__restrict__ out_b1, double *__restrict__ out_b2,
     ShadowResolve rs, unsigned long long *counters, PairEnt *__restrict__ spill, int lds_levels, int refill_min,
@@ -763,6 +916,8 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair_ref
         unsigned pend = 0;
         Ray r;
         SlabRay sv;
+        HalfBound hb;
+        hb.A = 0.; hb.R = 0.;
         double b1 = 0., b2 = 0.;
         r.o = r.d = mk3(0, 0, 0); r.mint = 0.; r.maxt = 0.;
         sv.invx = sv.invy = sv.invz = 0.; sv.negx = sv.negy = sv.negz = false; sv.negmask = 0; sv.fast = true;
@@ -776,12 +931,13 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair_ref
                 if (!have) {
                     k = base + (int)lane_prefix(waiting);
                     if (k < n) {
-                        if (order) k = order[first + k];      // the claimed position's ray (k_sort_rays); k < n still holds
+                        if (SORT) k = order[first + k];       // the claimed position's ray (k_sort_rays); k < n still holds
                         r = load_ray(rays, stride, first + k);
                         b1 = 0.; b2 = 0.;
                         result = ANY ? 0 : -1;
                         todo = 0; pend = 0;
                         sv = slab_ray(sc, r);
+                        if (HALF) hb = half_bound(sc, r, sv);
                         nray++;
                         bool walking;
                         if (sv.fast) walking = pair_root(sc, r, sv, ref, nvis);
@@ -799,7 +955,8 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair_ref
                 if (!more) break;
                 continue;                  // every claimed ray ended at once (missed the root): claim again
             }
-            if (have && pair_step<ANY, PT_PAIR_BLOCK>(sc, r, sv, stack, ref, todo, pend, result, b1, b2, nvis, ntri)) {
+            if (have && (HALF ? pair_step_h<ANY, PT_PAIR_BLOCK>(sc, r, sv, hb, stack, ref, todo, pend, result, b1, b2, nvis, ntri)
+                              : pair_step<ANY, PT_PAIR_BLOCK>(sc, r, sv, stack, ref, todo, pend, result, b1, b2, nvis, ntri))) {
                 store_result<ANY>(out, first + k, result, r, b1, b2);
                 have = false;
             }
@@ -811,9 +968,11 @@ __global__ __launch_bounds__(PT_PAIR_BLOCK, PT_PAIR_WAVES) void k_trace_pair_ref
 size_t pt_trace_pair_lds(int lds_levels) { return (size_t)lds_levels * PT_PAIR_BLOCK * sizeof(PairEnt); }
 size_t pt_trace_pair_spill_bytes(int levels, long grid_threads) { return (size_t)levels * (size_t)grid_threads * sizeof(PairEnt); }
 
-int pt_trace_pair_occupancy(bool any, int lds_levels) {
+int pt_trace_pair_occupancy(bool any, int lds_levels, bool half) {
     int nb = 0;
-    if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pair<true>, PT_PAIR_BLOCK, pt_trace_pair_lds(lds_levels));
+    if (half && any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pair_refill<true, true, false>, PT_PAIR_BLOCK, pt_trace_pair_lds(lds_levels));
+    else if (half) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pair_refill<false, true, false>, PT_PAIR_BLOCK, pt_trace_pair_lds(lds_levels));
+    else if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pair<true>, PT_PAIR_BLOCK, pt_trace_pair_lds(lds_levels));
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pair<false>, PT_PAIR_BLOCK, pt_trace_pair_lds(lds_levels));
     return nb > 0 ? nb : 2;
 }
@@ -830,9 +989,15 @@ hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid,
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
     if (!attr_set[dev][any ? 1 : 0]) {
-        const void *fns[2] = {any ? reinterpret_cast<const void *>(&k_trace_pair<true>) : reinterpret_cast<const void *>(&k_trace_pair<false>),
-                              any ? reinterpret_cast<const void *>(&k_trace_pair_refill<true>)
-                                  : reinterpret_cast<const void *>(&k_trace_pair_refill<false>)};
+        const void *fns[5] = {any ? reinterpret_cast<const void *>(&k_trace_pair<true>) : reinterpret_cast<const void *>(&k_trace_pair<false>),
+                              any ? reinterpret_cast<const void *>(&k_trace_pair_refill<true, false, false>)
+                                  : reinterpret_cast<const void *>(&k_trace_pair_refill<false, false, false>),
+                              any ? reinterpret_cast<const void *>(&k_trace_pair_refill<true, true, false>)
+                                  : reinterpret_cast<const void *>(&k_trace_pair_refill<false, true, false>),
+                              any ? reinterpret_cast<const void *>(&k_trace_pair_refill<true, false, true>)
+                                  : reinterpret_cast<const void *>(&k_trace_pair_refill<false, false, true>),
+                              any ? reinterpret_cast<const void *>(&k_trace_pair_refill<true, true, true>)
+                                  : reinterpret_cast<const void *>(&k_trace_pair_refill<false, true, true>)};
         for (const void *fn : fns) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
@@ -842,13 +1007,15 @@ hipError_t pt_launch_trace_pair(bool any, int lds_levels, void *spill, int grid,
     // lane refill needs the region cursors: segmented input of a launch with PT_TRACE_DYNAMIC
     const bool refill = seg_counts && (n_val & PT_TRACE_DYNAMIC) && (n_val & PT_TRACE_REFILL);
     if (refill_min < 1 || refill_min > 64) refill_min = PT_REFILL_MIN;
+    const bool half = (n_val & PT_TRACE_HALF) && sc.pairs_h != nullptr;
+#define PT_REFILL(A, H, S) hipLaunchKernelGGL((k_trace_pair_refill<A, H, S>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride, \
+                               seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, refill_min, order)
+#define PT_REFILL_S(A, H) do { if (order) PT_REFILL(A, H, true); else PT_REFILL(A, H, false); } while (0)
     if (refill) {
-        if (any)
-            hipLaunchKernelGGL((k_trace_pair_refill<true>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride,
-                               seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, refill_min, order);
-        else
-            hipLaunchKernelGGL((k_trace_pair_refill<false>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride,
-                               seg_counts, seg, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, refill_min, order);
+        if (any) { if (half) PT_REFILL_S(true, true); else PT_REFILL_S(true, false); }
+        else { if (half) PT_REFILL_S(false, true); else PT_REFILL_S(false, false); }
+#undef PT_REFILL_S
+#undef PT_REFILL
     } else if (any)
         hipLaunchKernelGGL((k_trace_pair<true>), dim3(grid), dim3(PT_PAIR_BLOCK), lds, stream, sc, rays, stride, seg_counts,
                            seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters, (PairEnt *)spill, lds_levels, order);

@@ -4,7 +4,7 @@
 # databases exceed what gpurun merges.   usage: scripts/prof_all.sh <round tag, e.g. r03> [workloads...]
 set -e
 R=${1:-r03}; shift || true
-WL=${@:-head c2 c4 c4sort c5 shard8 c1}
+WL=${@:-head c2 c4 c4full c4sort c5 shard8 c1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/profiles_out
 prof() {  # tag, bench args
@@ -35,6 +35,7 @@ for w in $WL; do
     head) prof head --steps 3 --warmup 1 ;;
     c2) prof c2 --workload c2 --steps 5 --warmup 2 ;;
     c4) prof c4 --workload c4 --spp 16 --steps 2 --warmup 1 ;;
+    c4full) PT_PAIR_HALF=0 prof c4full --workload c4 --spp 16 --steps 2 --warmup 1 ;;   # full-size (128-byte) pair records
     c4sort) PT_SORT_RAYS=3 prof c4sort --workload c4 --spp 16 --steps 2 --warmup 1 ;;
     c5) stats_only c5 "" --workload c5 --steps 2 --warmup 1 ;;
     shard8) PT_OVERLAP_FOR_STATS=1 stats_only shard8 "" --steps 6 --warmup 2 --shard-of 8 ;;

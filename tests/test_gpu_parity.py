@@ -141,6 +141,7 @@ def test_axis_parallel_rays_on_box_planes(torch_cuda, ctx, golden_dir):
                                   'PT_TRACE_DYNAMIC=1', 'PT_TRACE_DYNAMIC=0', 'PT_TRACE_META=4,PT_TRACE_DYNAMIC=0',
                                   'PT_TRACE_PACKET=3', 'PT_TRACE_PACKET=3,PT_OVERLAP=0',
                                   'PT_TRACE_PAIR=3,PT_PAIR_REFILL=1,PT_REFILL_MIN=5',
+                                  'PT_TRACE_PAIR=3,PT_PAIR_REFILL=1,PT_REFILL_MIN=5,PT_PAIR_HALF=0',
                                   'PT_TRACE_PAIR=3,PT_PAIR_REFILL=1,PT_REFILL_MIN=5,PT_OVERLAP=1,PT_TRACE_PACKET=0',
                                   'PT_TRACE_PAIR=3,PT_PAIR_REFILL=1,PT_TRACE_PACKET=3,PT_OVERLAP=1'])
 def test_trace_kernel_variants_are_bitwise_the_same(torch_cuda, golden_dir, head, knob):
@@ -211,6 +212,7 @@ def test_dynamic_chunk_assignment_changes_nothing(torch_cuda, golden_dir, head, 
     sub, spp = (0, R, 0, R), (2, 2)
     settings = [{'PT_TRACE_DYNAMIC': '0', 'PT_SHADE_DYNAMIC': '0'}, {},
                 {'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '0'}, {'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1'},
+                {'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1', 'PT_PAIR_HALF': '0'},
                 {'PT_TRACE_PACKET': '3'}, {'PT_TRACE_PACKET': '0'}]
     out = []
     for env in settings:

@@ -19,7 +19,8 @@ VARIANTS = [
     {'PT_OVERLAP': '0'},                                                    # the defaults on one stream
     {'PT_OVERLAP': '0', 'PT_BATCH': '4096'},                                # many wavefront batches
     {'PT_OVERLAP': '0', 'PT_TRACE_PACKET': '3'},                            # level-0 shadow rays per wave everywhere
-    {'PT_OVERLAP': '0', 'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1', 'PT_REFILL_MIN': '5'},   # pair walk, eager refill
+    {'PT_OVERLAP': '0', 'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1', 'PT_REFILL_MIN': '5'},   # pair walk, eager refill (half-size records)
+    {'PT_OVERLAP': '0', 'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1', 'PT_REFILL_MIN': '5', 'PT_PAIR_HALF': '0'},   # ... full-size records
     {'PT_OVERLAP': '0', 'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1', 'PT_TRACE_PACKET': '0', 'PT_PAIR_LDS_LEVELS': '2'},
     {'PT_OVERLAP': '0', 'PT_TRACE_TOP': '1', 'PT_TRACE_PAIR': '0'},
     {'PT_OVERLAP': '0', 'PT_TRACE_META': '4'},                              # k_trace_meta at sizes below its default threshold
