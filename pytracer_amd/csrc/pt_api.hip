@@ -1182,8 +1182,10 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
 
     // paths in flight per wavefront pass.  288 GB of HBM makes a whole 1024^2 x 64 spp render
     // (67 M paths, ~430 B of state each ≈ 29 GB) one batch, which amortises the latency-bound
-    // tails of the sparsely populated deep-bounce launches over 16x more work.
-    long batch = 1l << 26;
+    // tails of the sparsely populated deep-bounce launches over 16x more work.  Up to 2^28 paths (115 GB, within
+    // the half of the free memory taken below): the 10^6-triangle soup at 256 spp, 530 M paths, whose deep launches
+    // run ~1 ms each however few rays they hold, 1 377 ms in 8 batches of 2^26, 1 203 in 4, 1 179 in 2.
+    long batch = 1l << 28;
     if (const char *e = getenv("PT_BATCH")) { long v = atol(e); if (v >= 64) batch = v; }
     {
         size_t free_b = 0, total_b = 0;

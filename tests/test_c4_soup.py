@@ -5,6 +5,8 @@ The reference cannot build this scene in any reasonable time (hours of Python), 
 reference-exact builder (tests/test_bvh_build_cpu.py), and here (3) the oracle on a 20 k-triangle
 soup of the same recipe and (4) the 10^6-triangle scene through size-independent properties and a
 ray batch checked against the oracle (closest hit brute-forced for a subset)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -146,9 +148,10 @@ def test_million_triangle_soup(ctx):
 
 @pytest.mark.gpu
 def test_c4_full_frame_through_two_wavefront_batches(ctx):
-    """configs[3] at its real resolution through more than one REAL wavefront batch: 1920 x 1080 x 36 spp = 74.6 M
-    paths > 2^26, so pt_render runs two batches of the default size (tests elsewhere force small batches with
-    PT_BATCH); k_trace_pair_refill and k_trace_packet on the 2 M-node tree.  Census identities, and the four row
+    """configs[3] at its real resolution through more than one LARGE wavefront batch: 1920 x 1080 x 36 spp = 74.6 M
+    paths > 2^26, so with PT_BATCH = 2^26 (the default until it became 2^28; what configs[3] at 256 spp runs in is
+    two batches of 2^28) pt_render runs two batches, the first of 67 M paths — tests elsewhere force small batches;
+    k_trace_pair_refill and k_trace_packet on the 2 M-node tree.  Census identities, and the four row
     bands of the frame (one batch each) add up to the two-batch frame with an equal census."""
     import torch
     flat = W.c4_soup(10 ** 6)
@@ -169,9 +172,11 @@ def test_c4_full_frame_through_two_wavefront_batches(ctx):
         torch.cuda.synchronize()
         return acc, st.as_dict(), batches
     ctx.set_profiling(1)
+    os.environ['PT_BATCH'] = str(1 << 26)            # read by every pt_render call
     try:
         full, s1, batches = render([pa.tile_desc(0, res[0], 0, res[1], 0, xs * xs)], log=True)
     finally:
+        del os.environ['PT_BATCH']
         ctx.set_profiling(0)
     n = res[0] * res[1] * xs * xs
     assert n > (1 << 26) and {b for b, _ in batches} == {0, 1}
