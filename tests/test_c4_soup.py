@@ -189,3 +189,12 @@ def test_c4_full_frame_through_two_wavefront_batches(ctx):
     assert s4 == s1
     scale = float(full.abs().max())
     assert float((parts - full).abs().max()) <= 1e-11 * scale
+    # the default: ONE batch of 74.6 M paths (queue indices beyond 2^26; the cap is 2^28 paths within half of the free HBM)
+    ctx.set_profiling(1)
+    try:
+        one, s0, batches = render([pa.tile_desc(0, res[0], 0, res[1], 0, xs * xs)], log=True)
+    finally:
+        ctx.set_profiling(0)
+    assert {b for b, _ in batches} == {0}
+    assert s0 == s1
+    assert float((one - full).abs().max()) <= 1e-11 * scale
