@@ -49,6 +49,7 @@ struct pt_ctx {
     int trace_dynamic;       // PT_TRACE_DYNAMIC: 0 = static chunk assignment in the trace launches of a render, else (default) chunk cursors
     size_t brdf_bytes;
     int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
+    int meta_short;          // PT_TRACE_META_SHORT: 0 = never k_trace_meta_s (16-bit todo entries, two 512-thread workgroups per CU); else (default) where it fits
     int meta_stack;          // todo levels of k_trace_meta's LDS stacks (0: the tree's child words do not fit in LDS)
     int use_meta;            // k_trace_meta when the tree fits: PT_TRACE_META=0 never, 1 (default) closest-hit launches
                              // only (measured: closest -6 %, any +5 %), 2 both
@@ -207,6 +208,8 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     c->overlap = 1;
     if (const char *e = getenv("PT_OVERLAP")) c->overlap = atoi(e);
     c->trace_dynamic = -1;
+    c->meta_short = 1;
+    if (const char *e = getenv("PT_TRACE_META_SHORT")) c->meta_short = atoi(e);
     c->pair_refill = -1;
     c->use_packet = -1;
     if (const char *e = getenv("PT_TRACE_PACKET")) c->use_packet = atoi(e);
@@ -930,9 +933,16 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
     // the whole render 0.470 -> 0.421 ms; PT_TRACE_META=3 / 4 = closest / both at every size)
     const bool meta_size_ok = n_bound >= (1l << 20) || c->use_meta >= 3;
     if (c->meta_stack > 0 && c->use_top <= 0 && meta_size_ok && (c->use_meta == 2 || c->use_meta == 4 || ((c->use_meta == 1 || c->use_meta == 3) && !any))) {
+        *kid = PT_KERNEL_TRACE_META;
+        if (c->meta_short > 0 && c->sc.n_nodes <= 65535 &&
+            PT_METAS_PER_CU * pt_trace_meta_s_lds(c->meta_stack, c->sc.n_nodes) <= (size_t)160 * 1024 - 2048) {
+            const long blocks = (n_bound + PT_METAS_BLOCK - 1) / PT_METAS_BLOCK;
+            const int grid = (int)std::max<long>(1, std::min<long>(blocks, (long)PT_METAS_PER_CU * c->n_cu));
+            return pt_launch_trace_meta_s(any, c->meta_stack, grid, stream, c->sc, rays, stride, seg_counts, seg, n_val, out_prim,
+                                          out_t, out_b1, out_b2, rs, counters);
+        }
         const long blocks = (n_bound + 1023) / 1024;
         const int grid = (int)std::max<long>(1, std::min<long>(blocks, c->n_cu));
-        *kid = PT_KERNEL_TRACE_META;
         return pt_launch_trace_meta(any, c->meta_stack, grid, stream, c->sc, rays, stride, seg_counts, seg, n_val, out_prim,
                                     out_t, out_b1, out_b2, rs, counters);
     }

@@ -353,9 +353,9 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_top(DScene sc, const dou
 // loads (the box) plus one ds_read_b64 instead of four vector loads — the vector-memory pipe, which bounds the
 // walk (scripts/ta_micro.hip: 252 vs 210 G visits/s), carries a quarter less.  Same walk as
 // traverse<>, bit for bit.
-template <bool ANY, bool FAST>
+template <bool ANY, bool FAST, int BLOCK = PT_TOP_BLOCK, typename STK = int>
 __device__ __forceinline__ int traverse_meta_loop(const DScene &sc, const int2 *mlds, Ray &r, const SlabRay &sv,
-                                                  int *stack, double &b1o, double &b2o, unsigned &nvis, unsigned &ntri) {
+                                                  STK *stack, double &b1o, double &b2o, unsigned &nvis, unsigned &ntri) {
     int result = ANY ? 0 : -1;
     int todo_idx = 0, node_idx = 0;
     for (;;) {
@@ -381,9 +381,9 @@ __device__ __forceinline__ int traverse_meta_loop(const DScene &sc, const int2 *
         const bool neg = (sv.negmask >> (meta.y >> 16)) & 1;
         const int next = node_idx + 1;
         if (!inner && todo_idx == 0) break;
-        int *slot = stack + (inner ? todo_idx : todo_idx - 1) * PT_TOP_BLOCK;
-        if (inner) *slot = neg ? next : meta.x;
-        const int popped = *slot;
+        STK *slot = stack + (inner ? todo_idx : todo_idx - 1) * BLOCK;
+        if (inner) *slot = (STK)(neg ? next : meta.x);
+        const int popped = (int)*slot;
         node_idx = inner ? (neg ? meta.x : next) : popped;
         todo_idx += inner ? 1 : -1;
     }
@@ -416,6 +416,42 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_meta(DScene sc, const do
             const SlabRay sv = slab_ray(sc, r);
             res = sv.fast ? traverse_meta_loop<ANY, true>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri)
                           : traverse_meta_loop<ANY, false>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri);
+        }
+        store_result<ANY>(out, i, res, r, b1, b2);
+    });
+    if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
+}
+
+// k_trace_meta_s: the same kernel for trees of fewer than 2^16 nodes with 16-bit todo entries, which leaves LDS for TWO
+// workgroups of 512 threads per CU (each with its own copy of the table) instead of one of 1024: the same 4 waves per
+// SIMD, 4-5 % faster (headline closest-hit, one stream, ms per step with the level-0 packet launch: 1024 x 1 with 4-byte
+// or 2-byte entries 36.4, 512 x 2 34.8-35.3; 384 x 2 (3 waves) 38.6, 448 x 2 36.1, 576 x 2 38.7, 640 x 2 (5 waves) 41.1,
+// 768 x 1 37.4, 512 x 1 47.8).  pt_api.hip uses it wherever it fits (PT_TRACE_META_SHORT=0: the 1024-thread form).
+template <bool ANY>
+__global__ __launch_bounds__(PT_METAS_BLOCK, (PT_METAS_BLOCK / 256 * PT_METAS_PER_CU + (PT_METAS_BLOCK % 256 ? PT_METAS_PER_CU : 0))) void k_trace_meta_s(DScene sc, const double *__restrict__ rays, long stride,
+                                                                    const int *__restrict__ seg_counts, long seg, int n_val,
+                                                                    int *__restrict__ out_prim, double *__restrict__ out_t,
+                                                                    double *__restrict__ out_b1, double *__restrict__ out_b2,
+                                                                    ShadowResolve rs, unsigned long long *counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    int2 *mlds = reinterpret_cast<int2 *>(s_mem);
+    unsigned short *stack = reinterpret_cast<unsigned short *>(s_mem + pt_trace_meta_table_bytes(sc.n_nodes)) + threadIdx.x;
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(sc.node_meta);
+        int4 *dst = reinterpret_cast<int4 *>(s_mem);
+        for (int k = threadIdx.x; k < (sc.n_nodes + 1) / 2; k += PT_METAS_BLOCK) dst[k] = src[k];
+    }
+    __syncthreads();
+    unsigned nvis = 0, ntri = 0;
+    const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
+    const unsigned nray = for_each_ray<PT_METAS_BLOCK, 1>(seg_counts, seg, n_val, [&](long i) {
+        Ray r = load_ray(rays, stride, i);
+        double b1 = 0., b2 = 0.;
+        int res = ANY ? 0 : -1;
+        if (sc.n_nodes > 0) {
+            const SlabRay sv = slab_ray(sc, r);
+            res = sv.fast ? traverse_meta_loop<ANY, true, PT_METAS_BLOCK, unsigned short>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri)
+                          : traverse_meta_loop<ANY, false, PT_METAS_BLOCK, unsigned short>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri);
         }
         store_result<ANY>(out, i, res, r, b1, b2);
     });
@@ -1105,6 +1141,36 @@ hipError_t pt_launch_sort_rays(hipStream_t stream, const DScene &sc, const doubl
 
 size_t pt_trace_meta_lds(int stack, int n_nodes) {
     return pt_trace_meta_table_bytes(n_nodes) + (size_t)stack * PT_TOP_BLOCK * sizeof(int);
+}
+size_t pt_trace_meta_s_lds(int stack, int n_nodes) {
+    return pt_trace_meta_table_bytes(n_nodes) + (size_t)stack * PT_METAS_BLOCK * sizeof(unsigned short);
+}
+
+// two workgroups per CU; the grid in whole sets of PT_SEG waves (32 workgroups of 10 waves = 5 sets)
+hipError_t pt_launch_trace_meta_s(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                                  long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
+                                  double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
+    static bool attr_set[PT_MAX_DEVICES][2];
+    const size_t lds = pt_trace_meta_s_lds(stack, sc.n_nodes);
+    if (sc.n_nodes > 65535) return hipErrorInvalidValue;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!attr_set[dev][any ? 1 : 0]) {
+        hipError_t e = any ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_meta_s<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_meta_s<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[dev][any ? 1 : 0] = true;
+    }
+    if (seg_counts) grid = grid < 64 ? 32 : (grid / 32) * 32;
+    if (any)
+        hipLaunchKernelGGL((k_trace_meta_s<true>), dim3(grid), dim3(PT_METAS_BLOCK), lds, stream, sc, rays, stride, seg_counts,
+                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    else
+        hipLaunchKernelGGL((k_trace_meta_s<false>), dim3(grid), dim3(PT_METAS_BLOCK), lds, stream, sc, rays, stride, seg_counts,
+                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    return hipGetLastError();
 }
 
 hipError_t pt_launch_trace_meta(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
