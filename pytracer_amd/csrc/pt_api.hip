@@ -49,7 +49,8 @@ struct pt_ctx {
     int trace_dynamic;       // PT_TRACE_DYNAMIC: 0 = static chunk assignment in the trace launches of a render, else (default) chunk cursors
     size_t brdf_bytes;
     int top_stack;           // todo levels of k_trace_top's LDS stacks (0: top-of-tree staging off)
-    int meta_short;          // PT_TRACE_META_SHORT: 0 = never k_trace_meta_s (16-bit todo entries, two 512-thread workgroups per CU); else (default) where it fits
+    int meta_short;          // PT_TRACE_META_SHORT: 0 = never k_trace_meta_s (16-bit todo entries, small workgroups), 1 = its 512 x 2 form, 2 (default) = 256 x 4 with packed node words where they fit
+    bool meta_packable;      // every node's (offset, n_prim) fits the 32-bit word of k_trace_meta_s<.., true> (offset < 2^20, n_prim < 2^10)
     int meta_stack;          // todo levels of k_trace_meta's LDS stacks (0: the tree's child words do not fit in LDS)
     int use_meta;            // k_trace_meta when the tree fits: PT_TRACE_META=0 never, 1 (default) closest-hit launches
                              // only (measured: closest -6 %, any +5 %), 2 both
@@ -208,7 +209,7 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     c->overlap = 1;
     if (const char *e = getenv("PT_OVERLAP")) c->overlap = atoi(e);
     c->trace_dynamic = -1;
-    c->meta_short = 1;
+    c->meta_short = 2;
     if (const char *e = getenv("PT_TRACE_META_SHORT")) c->meta_short = atoi(e);
     c->pair_refill = -1;
     c->use_packet = -1;
@@ -716,7 +717,12 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     HIPCHK(c, upload(&c->d_nodes, nodes.data(), nodes.size()));
     {
         std::vector<int32_t> meta(2 * ((size_t)d->n_nodes + 1), 0);      // padded to a whole int4
-        for (int i = 0; i < d->n_nodes; i++) { meta[2 * (size_t)i] = nodes[i].offset; meta[2 * (size_t)i + 1] = nodes[i].nprim_axis; }
+        c->meta_packable = true;
+        for (int i = 0; i < d->n_nodes; i++) {
+            meta[2 * (size_t)i] = nodes[i].offset; meta[2 * (size_t)i + 1] = nodes[i].nprim_axis;
+            if (nodes[i].offset < 0 || nodes[i].offset >= (1 << 20) || (nodes[i].nprim_axis & 0xFFFF) >= (1 << 10) ||
+                (nodes[i].nprim_axis >> 16) < 0 || (nodes[i].nprim_axis >> 16) > 3) c->meta_packable = false;
+        }
         HIPCHK(c, upload(&c->d_meta, meta.data(), meta.size()));
     }
     // top of the tree for k_trace_top: the first K nodes in breadth-first order, K from the LDS left
@@ -934,12 +940,18 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
     const bool meta_size_ok = n_bound >= (1l << 20) || c->use_meta >= 3;
     if (c->meta_stack > 0 && c->use_top <= 0 && meta_size_ok && (c->use_meta == 2 || c->use_meta == 4 || ((c->use_meta == 1 || c->use_meta == 3) && !any))) {
         *kid = PT_KERNEL_TRACE_META;
-        if (c->meta_short > 0 && c->sc.n_nodes <= 65535 &&
-            PT_METAS_PER_CU * pt_trace_meta_s_lds(c->meta_stack, c->sc.n_nodes) <= (size_t)160 * 1024 - 2048) {
-            const long blocks = (n_bound + PT_METAS_BLOCK - 1) / PT_METAS_BLOCK;
-            const int grid = (int)std::max<long>(1, std::min<long>(blocks, (long)PT_METAS_PER_CU * c->n_cu));
-            return pt_launch_trace_meta_s(any, c->meta_stack, grid, stream, c->sc, rays, stride, seg_counts, seg, n_val, out_prim,
-                                          out_t, out_b1, out_b2, rs, counters);
+        // small workgroups with 16-bit todo entries where they fit (k_trace_meta_s): four of 256 threads with the node
+        // words packed into 32 bits, else two of 512; PT_TRACE_META_SHORT=1 stops at the latter, 0 keeps the 1024-thread form
+        const size_t lds_cu = (size_t)160 * 1024 - 2048;
+        if (c->meta_short > 0 && c->sc.n_nodes <= 65535) {
+            const bool packed = c->meta_short > 1 && c->meta_packable && 4 * pt_trace_meta_s_lds(c->meta_stack, c->sc.n_nodes, true) <= lds_cu;
+            if (packed || 2 * pt_trace_meta_s_lds(c->meta_stack, c->sc.n_nodes, false) <= lds_cu) {
+                const int bt = packed ? 256 : 512;
+                const long blocks = (n_bound + bt - 1) / bt;
+                const int grid = (int)std::max<long>(1, std::min<long>(blocks, (long)(1024 / bt) * c->n_cu));
+                return pt_launch_trace_meta_s(any, packed, c->meta_stack, grid, stream, c->sc, rays, stride, seg_counts, seg, n_val,
+                                              out_prim, out_t, out_b1, out_b2, rs, counters);
+            }
         }
         const long blocks = (n_bound + 1023) / 1024;
         const int grid = (int)std::max<long>(1, std::min<long>(blocks, c->n_cu));

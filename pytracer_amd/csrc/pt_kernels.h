@@ -157,17 +157,14 @@ hipError_t pt_launch_trace_packet(bool any, int stack, int grid, hipStream_t str
 // k_trace_meta: child/primitive words of all nodes in LDS (small trees); bytes of the table and of the whole block
 __host__ __device__ inline size_t pt_trace_meta_table_bytes(int n_nodes) { return (((size_t)n_nodes * 8) + 15) & ~(size_t)15; }
 size_t pt_trace_meta_lds(int stack, int n_nodes);
-#ifndef PT_METAS_BLOCK
-#define PT_METAS_BLOCK 512
-#define PT_METAS_PER_CU 2
-#endif
-size_t pt_trace_meta_s_lds(int stack, int n_nodes);      // k_trace_meta_s: 16-bit todo entries, 512-thread workgroups, two per CU
-hipError_t pt_launch_trace_meta_s(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
-                                  long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
-                                  double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 hipError_t pt_launch_trace_meta(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
                                 long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                                 double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
+// k_trace_meta_s: 16-bit todo entries; two 512-thread workgroups per CU, or (packed: the node word in 32 bits) four of 256
+size_t pt_trace_meta_s_lds(int stack, int n_nodes, bool packed);
+hipError_t pt_launch_trace_meta_s(bool any, bool packed, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+                                  long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
+                                  double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);
 hipError_t pt_launch_trace_top(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
                                long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                                double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters);

@@ -5,6 +5,7 @@
 // No MFMA anywhere: ray–box / ray–triangle tests and BSDF evaluation are not dense
 // contractions; the bounding resource is cache/HBM bandwidth and divergent fp64 VALU.
 #include "pt_kernels.h"
+#include <type_traits>
 
 // =========================================================================================
 // BVH traversal.  One lane per ray; the per-lane todo stack of bvh.py:332 lives in LDS as
@@ -353,15 +354,21 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_top(DScene sc, const dou
 // loads (the box) plus one ds_read_b64 instead of four vector loads — the vector-memory pipe, which bounds the
 // walk (scripts/ta_micro.hip: 252 vs 210 G visits/s), carries a quarter less.  Same walk as
 // traverse<>, bit for bit.
-template <bool ANY, bool FAST, int BLOCK = PT_TOP_BLOCK, typename STK = int>
-__device__ __forceinline__ int traverse_meta_loop(const DScene &sc, const int2 *mlds, Ray &r, const SlabRay &sv,
+// the staged (offset, n_prim | axis << 16) word of a node: as it is, or packed into 32 bits (offset 20, n_prim 10, axis 2)
+__device__ __forceinline__ int2 meta_at(const int2 *t, int i) { return t[i]; }
+__device__ __forceinline__ int2 meta_at(const unsigned *t, int i) {
+    const unsigned m = t[i];
+    return make_int2((int)(m & 0xFFFFFu), (int)(((m >> 20) & 0x3FFu) | ((m >> 30) << 16)));
+}
+template <bool ANY, bool FAST, int BLOCK = PT_TOP_BLOCK, typename STK = int, typename TAB = int2>
+__device__ __forceinline__ int traverse_meta_loop(const DScene &sc, const TAB *mlds, Ray &r, const SlabRay &sv,
                                                   STK *stack, double &b1o, double &b2o, unsigned &nvis, unsigned &ntri) {
     int result = ANY ? 0 : -1;
     int todo_idx = 0, node_idx = 0;
     for (;;) {
         const double2 *q = reinterpret_cast<const double2 *>(sc.nodes + node_idx);
         const double2 n0 = q[0], n1 = q[1], n2 = q[2];
-        const int2 meta = mlds[node_idx];
+        const int2 meta = meta_at(mlds, node_idx);
         nvis++;
         const bool hitbox = slab_hit<FAST>(n0, n1, n2, r, sv);
         const int nprim = meta.y & 0xFFFF;
@@ -422,36 +429,46 @@ __global__ __launch_bounds__(PT_TOP_BLOCK) void k_trace_meta(DScene sc, const do
     if (counters) trace_count<ANY>(counters, nvis, ntri, nray);
 }
 
-// k_trace_meta_s: the same kernel for trees of fewer than 2^16 nodes with 16-bit todo entries, which leaves LDS for TWO
-// workgroups of 512 threads per CU (each with its own copy of the table) instead of one of 1024: the same 4 waves per
-// SIMD, 4-5 % faster (headline closest-hit, one stream, ms per step with the level-0 packet launch: 1024 x 1 with 4-byte
-// or 2-byte entries 36.4, 512 x 2 34.8-35.3; 384 x 2 (3 waves) 38.6, 448 x 2 36.1, 576 x 2 38.7, 640 x 2 (5 waves) 41.1,
-// 768 x 1 37.4, 512 x 1 47.8).  pt_api.hip uses it wherever it fits (PT_TRACE_META_SHORT=0: the 1024-thread form).
-template <bool ANY>
-__global__ __launch_bounds__(PT_METAS_BLOCK, (PT_METAS_BLOCK / 256 * PT_METAS_PER_CU + (PT_METAS_BLOCK % 256 ? PT_METAS_PER_CU : 0))) void k_trace_meta_s(DScene sc, const double *__restrict__ rays, long stride,
-                                                                    const int *__restrict__ seg_counts, long seg, int n_val,
-                                                                    int *__restrict__ out_prim, double *__restrict__ out_t,
-                                                                    double *__restrict__ out_b1, double *__restrict__ out_b2,
-                                                                    ShadowResolve rs, unsigned long long *counters) {
+// k_trace_meta_s: the same kernel for trees of fewer than 2^16 nodes with 16-bit todo entries, which leaves LDS for
+// several small workgroups per CU (each with its own copy of the table) instead of one of 1024 threads: the same 4 waves
+// per SIMD, 5-6 % faster (headline closest-hit, one stream, ms per step with the level-0 packet launch: 1024 x 1 with
+// 4-byte or 2-byte entries 36.4-36.8; 512 x 2 34.8-35.3; 384 x 2 (3 waves) 38.6, 448 x 2 36.1, 576 x 2 38.7, 640 x 2
+// (5 waves) 41.1, 768 x 1 37.4, 512 x 1 47.8).  PACKED: the node word in 32 bits (meta_at: offset 20, n_prim 10, axis 2
+// bits; pt_api.hip checks that the tree fits), half the table, so FOUR workgroups of 256 threads fit: 34.4 (512 x 2
+// packed 34.7).  pt_api.hip uses the smallest form that fits (PT_TRACE_META_SHORT=0: the 1024-thread form, 1: 512 x 2).
+template <bool ANY, int BLOCK, bool PACKED>
+__global__ __launch_bounds__(BLOCK, 4) void k_trace_meta_s(DScene sc, const double *__restrict__ rays, long stride,
+                                                           const int *__restrict__ seg_counts, long seg, int n_val,
+                                                           int *__restrict__ out_prim, double *__restrict__ out_t,
+                                                           double *__restrict__ out_b1, double *__restrict__ out_b2,
+                                                           ShadowResolve rs, unsigned long long *counters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
-    int2 *mlds = reinterpret_cast<int2 *>(s_mem);
-    unsigned short *stack = reinterpret_cast<unsigned short *>(s_mem + pt_trace_meta_table_bytes(sc.n_nodes)) + threadIdx.x;
-    {
+    typedef typename std::conditional<PACKED, unsigned, int2>::type TAB;
+    TAB *mlds = reinterpret_cast<TAB *>(s_mem);
+    unsigned short *stack = reinterpret_cast<unsigned short *>(s_mem + pt_trace_meta_table_bytes(sc.n_nodes) / (PACKED ? 2 : 1)) + threadIdx.x;
+    if (PACKED) {
+        const int2 *src = reinterpret_cast<const int2 *>(sc.node_meta);
+        unsigned *dst = reinterpret_cast<unsigned *>(s_mem);
+        for (int k = threadIdx.x; k < sc.n_nodes; k += BLOCK) {
+            const int2 m = src[k];
+            dst[k] = (unsigned)m.x | ((unsigned)(m.y & 0x3FF) << 20) | ((unsigned)(m.y >> 16) << 30);
+        }
+    } else {
         const int4 *src = reinterpret_cast<const int4 *>(sc.node_meta);
         int4 *dst = reinterpret_cast<int4 *>(s_mem);
-        for (int k = threadIdx.x; k < (sc.n_nodes + 1) / 2; k += PT_METAS_BLOCK) dst[k] = src[k];
+        for (int k = threadIdx.x; k < (sc.n_nodes + 1) / 2; k += BLOCK) dst[k] = src[k];
     }
     __syncthreads();
     unsigned nvis = 0, ntri = 0;
     const TraceOut out = {out_prim, out_t, out_b1, out_b2, rs};
-    const unsigned nray = for_each_ray<PT_METAS_BLOCK, 1>(seg_counts, seg, n_val, [&](long i) {
+    const unsigned nray = for_each_ray<BLOCK, 1>(seg_counts, seg, n_val, [&](long i) {
         Ray r = load_ray(rays, stride, i);
         double b1 = 0., b2 = 0.;
         int res = ANY ? 0 : -1;
         if (sc.n_nodes > 0) {
             const SlabRay sv = slab_ray(sc, r);
-            res = sv.fast ? traverse_meta_loop<ANY, true, PT_METAS_BLOCK, unsigned short>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri)
-                          : traverse_meta_loop<ANY, false, PT_METAS_BLOCK, unsigned short>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri);
+            res = sv.fast ? traverse_meta_loop<ANY, true, BLOCK, unsigned short, TAB>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri)
+                          : traverse_meta_loop<ANY, false, BLOCK, unsigned short, TAB>(sc, mlds, r, sv, stack, b1, b2, nvis, ntri);
         }
         store_result<ANY>(out, i, res, r, b1, b2);
     });
@@ -1142,34 +1159,34 @@ hipError_t pt_launch_sort_rays(hipStream_t stream, const DScene &sc, const doubl
 size_t pt_trace_meta_lds(int stack, int n_nodes) {
     return pt_trace_meta_table_bytes(n_nodes) + (size_t)stack * PT_TOP_BLOCK * sizeof(int);
 }
-size_t pt_trace_meta_s_lds(int stack, int n_nodes) {
-    return pt_trace_meta_table_bytes(n_nodes) + (size_t)stack * PT_METAS_BLOCK * sizeof(unsigned short);
+size_t pt_trace_meta_s_lds(int stack, int n_nodes, bool packed) {
+    return pt_trace_meta_table_bytes(n_nodes) / (packed ? 2 : 1) + (size_t)stack * (packed ? 256 : 512) * sizeof(unsigned short);
 }
 
-// two workgroups per CU; the grid in whole sets of PT_SEG waves (32 workgroups of 10 waves = 5 sets)
-hipError_t pt_launch_trace_meta_s(bool any, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
+// packed: four 256-thread workgroups per CU, else two of 512; the grid in whole sets of PT_SEG waves
+hipError_t pt_launch_trace_meta_s(bool any, bool packed, int stack, int grid, hipStream_t stream, const DScene &sc, const double *rays,
                                   long stride, const int *seg_counts, long seg, int n_val, int *out_prim, double *out_t,
                                   double *out_b1, double *out_b2, const ShadowResolve &rs, unsigned long long *counters) {
-    static bool attr_set[PT_MAX_DEVICES][2];
-    const size_t lds = pt_trace_meta_s_lds(stack, sc.n_nodes);
+    static bool attr_set[PT_MAX_DEVICES];
+    const size_t lds = pt_trace_meta_s_lds(stack, sc.n_nodes, packed);
     if (sc.n_nodes > 65535) return hipErrorInvalidValue;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PT_MAX_DEVICES) return hipErrorInvalidDevice;
-    if (!attr_set[dev][any ? 1 : 0]) {
-        hipError_t e = any ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_meta_s<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_meta_s<false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set[dev][any ? 1 : 0] = true;
+    if (!attr_set[dev]) {
+        const void *fns[4] = {reinterpret_cast<const void *>(&k_trace_meta_s<true, 512, false>), reinterpret_cast<const void *>(&k_trace_meta_s<false, 512, false>),
+                              reinterpret_cast<const void *>(&k_trace_meta_s<true, 256, true>), reinterpret_cast<const void *>(&k_trace_meta_s<false, 256, true>)};
+        for (const void *fn : fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        attr_set[dev] = true;
     }
-    if (seg_counts) grid = grid < 64 ? 32 : (grid / 32) * 32;
-    if (any)
-        hipLaunchKernelGGL((k_trace_meta_s<true>), dim3(grid), dim3(PT_METAS_BLOCK), lds, stream, sc, rays, stride, seg_counts,
-                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
-    else
-        hipLaunchKernelGGL((k_trace_meta_s<false>), dim3(grid), dim3(PT_METAS_BLOCK), lds, stream, sc, rays, stride, seg_counts,
-                           seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters);
+    if (seg_counts) grid = grid < 128 ? 64 : (grid / 64) * 64;
+#define PT_METAS(A, B, P) hipLaunchKernelGGL((k_trace_meta_s<A, B, P>), dim3(grid), dim3(B), lds, stream, sc, rays, stride, seg_counts, \
+                                             seg, n_val, out_prim, out_t, out_b1, out_b2, rs, counters)
+    if (packed) { if (any) PT_METAS(true, 256, true); else PT_METAS(false, 256, true); }
+    else { if (any) PT_METAS(true, 512, false); else PT_METAS(false, 512, false); }
+#undef PT_METAS
     return hipGetLastError();
 }
 

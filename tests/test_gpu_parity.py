@@ -137,7 +137,7 @@ def test_axis_parallel_rays_on_box_planes(torch_cuda, ctx, golden_dir):
     assert (gs.node_visits, gs.tri_tests) == (os_.node_visits, os_.tri_tests)
 
 
-@pytest.mark.parametrize('knob', ['PT_TRACE_TOP=1', 'PT_TRACE_META=4', 'PT_TRACE_META=4,PT_TRACE_META_SHORT=0', 'PT_TRACE_META=3', 'PT_TRACE_META=0', 'PT_TRACE_PAIR=3',
+@pytest.mark.parametrize('knob', ['PT_TRACE_TOP=1', 'PT_TRACE_META=4', 'PT_TRACE_META=4,PT_TRACE_META_SHORT=0', 'PT_TRACE_META=4,PT_TRACE_META_SHORT=1', 'PT_TRACE_META=3', 'PT_TRACE_META=0', 'PT_TRACE_PAIR=3',
                                   'PT_TRACE_DYNAMIC=1', 'PT_TRACE_DYNAMIC=0', 'PT_TRACE_META=4,PT_TRACE_DYNAMIC=0',
                                   'PT_TRACE_PACKET=3', 'PT_TRACE_PACKET=3,PT_OVERLAP=0',
                                   'PT_TRACE_PAIR=3,PT_PAIR_REFILL=1,PT_REFILL_MIN=5',

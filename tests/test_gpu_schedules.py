@@ -23,7 +23,8 @@ VARIANTS = [
     {'PT_OVERLAP': '0', 'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1', 'PT_REFILL_MIN': '5', 'PT_PAIR_HALF': '0'},   # ... full-size records
     {'PT_OVERLAP': '0', 'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1', 'PT_TRACE_PACKET': '0', 'PT_PAIR_LDS_LEVELS': '2'},
     {'PT_OVERLAP': '0', 'PT_TRACE_TOP': '1', 'PT_TRACE_PAIR': '0'},
-    {'PT_OVERLAP': '0', 'PT_TRACE_META': '4'},                              # k_trace_meta_s (16-bit stacks, 2 x 512 threads per CU) at sizes below its default threshold
+    {'PT_OVERLAP': '0', 'PT_TRACE_META': '4'},                              # k_trace_meta_s (16-bit stacks, packed node words, 4 x 256 threads per CU) at sizes below its default threshold
+    {'PT_OVERLAP': '0', 'PT_TRACE_META': '4', 'PT_TRACE_META_SHORT': '1'},   # ... its 512 x 2 form with 8-byte node words
     {'PT_OVERLAP': '0', 'PT_TRACE_META': '4', 'PT_TRACE_META_SHORT': '0'},   # ... the 1024-thread form with 4-byte stacks
     {'PT_OVERLAP': '1', 'PT_TRACE_PAIR': '3', 'PT_SORT_RAYS': '3', 'PT_SORT_WINDOW': '256'},   # ray binning before the pair walks
     # the two-stream schedule (the default, and the headline's): double-buffered shadow queues, ev_shade / ev_any

@@ -24,7 +24,7 @@ def short(name):
     m = re.match(r'(?:void )?(k_trace)<(\d+), (true|false)>', name)
     if m:
         return 'k_trace<%s>' % ('any' if m.group(3) == 'true' else 'closest')
-    m = re.match(r'(?:void )?k_trace_(?:meta_s|meta|top|pair_refill|pair|packet|lds)<(true|false)(?:, (?:true|false))*>', name)   # other fetch forms of the same walk
+    m = re.match(r'(?:void )?k_trace_(?:meta_s|meta|top|pair_refill|pair|packet|lds)<(true|false)(?:, \w+)*>', name)   # other fetch forms of the same walk
     if m:
         return 'k_trace<%s>' % ('any' if m.group(1) == 'true' else 'closest')
     # k_shade<KIND, EXT, real type[, LOBES]>: EXT 1 textures / uvs, 2 measured BRDF
