@@ -52,8 +52,9 @@ struct pt_ctx {
     int meta_short;          // PT_TRACE_META_SHORT: 0 = never k_trace_meta_s (16-bit todo entries, small workgroups), 1 = its 512 x 2 form, 2 (default) = 256 x 4 with packed node words where they fit
     bool meta_packable;      // every node's (offset, n_prim) fits the 32-bit word of k_trace_meta_s<.., true> (offset < 2^20, n_prim < 2^10)
     int meta_stack;          // todo levels of k_trace_meta's LDS stacks (0: the tree's child words do not fit in LDS)
-    int use_meta;            // k_trace_meta when the tree fits: PT_TRACE_META=0 never, 1 (default) closest-hit launches
-                             // only (measured: closest -6 %, any +5 %), 2 both
+    int use_meta;            // k_trace_meta(_s) when the tree fits: PT_TRACE_META=0 never, 1 closest-hit launches only,
+                             // 2 (default) both: with 1024-thread workgroups any-hit lost 5 %, with k_trace_meta_s'
+                             // four of 256 threads it gains 4 % (15.9 -> 15.2 ms, the step 64.35 -> 64.0)
     int stack_need;          // deepest leaf = max simultaneous todo entries (bvh.py:332 allows 64)
     bool has_spec_reflect;   // any material with a SpecularReflection lobe (Direct recursion)
     bool diffuse_back;       // hits listed in two classes by lobe set, the back list shaded by the diffuse-only kernel
@@ -197,7 +198,7 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
     CREATE_CHK(hipMalloc((void **)&c->d_counts, 6 * PT_CNT_BLOCK * sizeof(int)));
     c->use_top = -1;
     if (const char *e = getenv("PT_TRACE_TOP")) c->use_top = atoi(e);
-    c->use_meta = 1;
+    c->use_meta = 2;
     if (const char *e = getenv("PT_TRACE_META")) c->use_meta = atoi(e);
     c->use_pair = -1;
     if (const char *e = getenv("PT_TRACE_PAIR")) c->use_pair = atoi(e);
