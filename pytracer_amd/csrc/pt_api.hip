@@ -71,6 +71,7 @@ struct pt_ctx {
     long cap, sh_cap;
     void *ws;
     size_t ws_bytes;
+    long ws_paths; int ws_spv;   // the batch size and shadow rays per vertex the workspace was sized for
     Queue q[2];
     ShadowQueue sh[2];       // double-buffered: the any-hit trace of level k runs on `aux` beside level k+1's closest-hit
     PathState st;            // trace and shading, which fills the other buffer
@@ -1089,6 +1090,7 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv, int gshift) {
     const long cap = seg * PT_SEG, sh_cap = cap * spv;
     if (c->ws && c->cap == cap && c->sh_cap == sh_cap) return PT_OK;
     if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; }
+    c->cap = c->sh_cap = 0; c->ws_bytes = 0; c->ws_paths = 0;
     size_t bytes = 0;
     auto need = [&](size_t b) { size_t off = bytes; bytes += align_up(b); return off; };
     size_t off_q[2][6];
@@ -1111,7 +1113,11 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv, int gshift) {
     size_t off_hit = need(cap * sizeof(int));
     size_t off_esc = need(cap * sizeof(int));
     size_t off_oq = need(cap * sizeof(int)), off_osh[2] = {need(sh_cap * sizeof(int)), need(sh_cap * sizeof(int))};
-    HIPCHK(c, hipMalloc(&c->ws, bytes));
+    {
+        hipError_t e = hipMalloc(&c->ws, bytes);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); c->ws = nullptr; return PT_ERR_CAPACITY; }   // the caller tries a smaller batch
+        HIPCHK(c, e);
+    }
     char *b = (char *)c->ws;
     for (int k = 0; k < 2; k++) {
         Queue &q = c->q[k];
@@ -1131,7 +1137,7 @@ static int ensure_workspace(pt_ctx *c, long paths, int spv, int gshift) {
     c->hit_idx = (int *)(b + off_hit);
     c->order_q = (int *)(b + off_oq);
     for (int k = 0; k < 2; k++) c->order_sh[k] = (int *)(b + off_osh[k]);
-    c->cap = cap; c->sh_cap = sh_cap; c->ws_bytes = bytes;
+    c->cap = cap; c->sh_cap = sh_cap; c->ws_bytes = bytes; c->ws_paths = paths; c->ws_spv = spv;
     return PT_OK;
 }
 
@@ -1208,6 +1214,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
     // tails of the sparsely populated deep-bounce launches over 16x more work.  Up to 2^28 paths (115 GB, within
     // the half of the free memory taken below): the 10^6-triangle soup at 256 spp, 530 M paths, whose deep launches
     // run ~1 ms each however few rays they hold, 1 377 ms in 8 batches of 2^26, 1 203 in 4, 1 179 in 2.
+    const int spv = ig->kind == PT_INTEG_DIRECT ? std::max(c->shadow_per_vertex_direct, 1)
+                    : (ig->kind == PT_INTEG_WHITTED ? std::max(c->sc.n_lights, 1) : 1);
     long batch = 1l << 28;
     if (const char *e = getenv("PT_BATCH")) { long v = atol(e); if (v >= 64) batch = v; }
     {
@@ -1216,18 +1224,30 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
             const size_t per_path = 8 * 8 * 2 + 4 * 2 * 2 + 8 * 3 * 2 + 2 * (8 * 11 + 4) * (size_t)std::max(1, ig->kind == PT_INTEG_DIRECT ? c->shadow_per_vertex_direct : (ig->kind == PT_INTEG_WHITTED ? c->sc.n_lights : 1)) + 8 * 8 + 4;
             const size_t budget = (free_b + c->ws_bytes) / 2;     // leave half of what is free to the caller
             const long fit = (long)(budget / per_path);
-            if (fit < batch) batch = std::max(fit, 1l << 16);
+            if (fit < batch) {
+                // bounded by memory.  What is free moves by the allocation granule with every call, so the same render
+                // would get a slightly different batch each time and free and allocate ~100 GB per call (and fail now
+                // and then: the soup bench's second context did): a workspace the context already holds for this kind
+                // of render is kept as long as it is at least half of what would fit now
+                if (c->ws && c->ws_spv == spv && c->ws_paths <= batch && c->ws_paths >= fit / 2) batch = c->ws_paths;
+                else batch = std::max(fit, 1l << 16);
+            }
         }
     }
     batch = std::min(batch, total);
     batch = (batch + 63) & ~63l;
-    const int spv = ig->kind == PT_INTEG_DIRECT ? std::max(c->shadow_per_vertex_direct, 1)
-                    : (ig->kind == PT_INTEG_WHITTED ? std::max(c->sc.n_lights, 1) : 1);
     // chunk-group size of the segmented queues: up to 64 chunks (the 4096-entry sort window), fewer
     // for small batches so that every region still gets several groups
     int gshift = 0;
-    while (gshift < 6 && ((batch / 64) >> (gshift + 1)) >= 4 * PT_SEG) gshift++;
-    int rc = ensure_workspace(c, batch, spv, gshift);
+    int rc;
+    for (;;) {
+        gshift = 0;
+        while (gshift < 6 && ((batch / 64) >> (gshift + 1)) >= 4 * PT_SEG) gshift++;
+        rc = ensure_workspace(c, batch, spv, gshift);
+        if (rc != PT_ERR_CAPACITY || batch <= (1l << 20)) break;
+        batch = ((batch / 2) + 63) & ~63l;          // hipMemGetInfo promised more than hipMalloc gives: half the batch
+    }
+    if (rc == PT_ERR_CAPACITY) return fail(c, PT_ERR_HIP, "no memory for a wavefront batch of %ld paths", batch);
     if (rc != PT_OK) return rc;
     memcpy(c->st.le, c->sc.le_sum, sizeof(c->st.le));
 

@@ -147,3 +147,49 @@ def test_one_process_drives_eight_contexts(golden_dir):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_render_when_device_memory_is_short(golden_dir):
+    """pt_render takes at most half of the free device memory for its wavefront batch.  With all but ~6 GB of the GPU
+    taken by the caller, a 16.8 M-path render runs in several batches; rendered twice in that state (the second call
+    keeps the first call's workspace: what is free moves by the allocation granule, and a batch re-fitted to it would
+    free and allocate the whole workspace per call) it equals the one-batch render, census included."""
+    import torch
+    from pytracer_amd import host
+    from pytracer_amd._lib import Context
+    flat = pa.flat_scene_from_npz(dict(np.load(os.path.join(golden_dir, 'head_mesh_scene.npz'))))
+    cam, film = host.head_mesh_camera_film(1024, 1024)
+    smp = pa.sampler_desc(0, 1024, 0, 1024, 4, 4, True, 0)
+    tile = pa.tile_desc(0, 1024, 0, 1024, 0, 16)
+    integ = pa.integrator_desc(A.PT_INTEG_PATH, 5, False)
+
+    def render(ctx):
+        acc = torch.zeros((film.y_cnt, film.x_cnt, 4), dtype=torch.float64, device='cuda')
+        st = A.pt_stats()
+        ctx.render(cam, film, smp, integ, tile, acc, stats=st)
+        torch.cuda.synchronize()
+        n_batches = len({r['batch'] for r in ctx.launch_log()})
+        return acc, st.as_dict(), n_batches
+
+    ref_ctx = Context(0)
+    ref_ctx.upload(flat)
+    ref_ctx.set_profiling(1)
+    ref, s_ref, nb = render(ref_ctx)
+    assert nb == 1
+    ref_ctx.close()
+    torch.cuda.empty_cache()
+    ctx = Context(0)
+    ctx.upload(flat)
+    ctx.set_profiling(1)
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(free - (6 << 30), dtype=torch.uint8, device='cuda')
+    try:
+        for _ in range(2):
+            acc, s, nb = render(ctx)
+            assert nb >= 3
+            assert s == s_ref
+            assert float((acc - ref).abs().max()) <= 1e-11 * float(ref.abs().max())
+    finally:
+        del hog
+        ctx.close()
+        torch.cuda.empty_cache()
