@@ -291,7 +291,12 @@ int pt_intersect_static(pt_ctx *ctx, const double *rays, int64_t n, int any_hit,
  *                 rng() draws are the counter hash u(r,k) documented in DESIGN.md.
  *   film_accum    device f64 [y_cnt][x_cnt][4] = Lxyz[3], weight_sum; ADDED to.
  *   sample_L      device f64 [n_tile_samples][3] or NULL: per-sample radiance after guards.
- *   stats         host, may be NULL: counters are ADDED. */
+ *   stats         host, may be NULL: counters are ADDED.
+ * Device memory: the tile is rendered in wavefront batches of up to 2^28 paths (~460 bytes of queue and path state
+ * each; the environment variable PT_BATCH sets another limit) and never more than fit in HALF of the device memory
+ * that is free at the call; the workspace is allocated by the context (hipMalloc, at the first call and when the
+ * batch size changes), kept until pt_ctx_destroy, and kept as it is by later calls that are bounded by memory.  If
+ * hipMalloc refuses it the batch is halved (down to 2^20 paths) before the call fails with PT_ERR_HIP. */
 int pt_render(pt_ctx *ctx, const pt_camera *cam, const pt_film_desc *film,
               const pt_sampler_desc *sampler, const pt_integrator_desc *integ,
               const pt_tile *tile, const double *sample_table, int32_t table_dims,
