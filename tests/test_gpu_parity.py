@@ -473,3 +473,46 @@ def test_errors_are_reported(torch_cuda, golden_dir):
         assert e.value.code == A.PT_ERR_ARG
     finally:
         c.close()
+
+
+@pytest.mark.parametrize('short', ['2', '1', '0'])
+def test_meta_walk_on_a_tree_with_a_leaf_too_large_to_pack(torch_cuda, golden_dir, short):
+    """The C ABI takes any linearised tree.  A leaf of 1 500 primitives does not fit the 10-bit count of the packed node
+    word of k_trace_meta_s<.., 256, true> (pt_scene_upload checks every node): the launch falls back to the 512-thread
+    form with 8-byte node words (PT_TRACE_META_SHORT=2, the default, and =1) or runs the 1024-thread form (=0); hits and
+    census equal the oracle's on the same tree."""
+    import oracle_lib as O
+    from pytracer_amd._lib import Context
+    d = load(golden_dir, 'bvh_soup2000.npz')
+    base = pa.flat_scene_from_npz(d)
+    tv = base.tri_verts
+    assert len(tv) == 2000
+
+    def box(a):
+        p = a.reshape(-1, 3)
+        return np.concatenate([p.min(0), p.max(0)])
+    bounds = np.stack([box(tv), box(tv[:1500]), box(tv[1500:])])
+    meta = np.array([[2, 0, 0], [0, 1500, 0], [1500, 500, 0]], np.int32)
+    flat = pa.FlatScene(bounds, meta, tv, base.tri_mat, base.tri_flip, base.material_lobes, base.light_records)
+    rays = np.ascontiguousarray(d['rays'].T)[:, :1024]
+    env = {'PT_TRACE_META': '4', 'PT_TRACE_META_SHORT': short}
+    os.environ.update(env)
+    try:
+        c = Context(0)
+    finally:
+        for k in env:
+            del os.environ[k]
+    try:
+        c.upload(flat)
+        osc = O.OracleScene(flat)
+        for any_hit in (False, True):
+            gs, os_ = A.pt_stats(), A.pt_stats()
+            g = gpu_intersect(torch_cuda, c, rays, any_hit, gs)
+            o = osc.intersect(rays, any_hit=any_hit, stats=os_)
+            assert np.array_equal(g[0], o[0])
+            if not any_hit:
+                assert (g[0] >= 0).sum() > 100
+                assert np.array_equal(g[1], o[1])
+            assert (gs.node_visits, gs.tri_tests) == (os_.node_visits, os_.tri_tests)
+    finally:
+        c.close()
