@@ -62,7 +62,8 @@ struct pt_ctx {
                              // octant before k_trace_pair(_refill) traces them (k_sort_rays); unset (-1) = by tree size
     int sort_window, sort_mode;   // PT_SORT_WINDOW (entries per sorted window), PT_SORT_MODE (key arrangement | grid bits << 4)
     int *order_q, *order_sh[2];   // [cap] / [sh_cap]: trace order of the continuation queue / the two shadow queues
-    int lobe_sets;           // PT_SHADE_LOBESETS: 1 = the diffuse class is shaded by the kernel compiled for it; 0 = the classes only
+    int lobe_sets;           // PT_SHADE_LOBESETS: the diffuse class is shaded by the kernel compiled for it: 1 (default) on the levels
+                             // large enough to pay for a second launch, 2 on every level, 0 never (the classes only)
                              // order the hit lists and one kernel shades both
     bool all_diffuse;        // no material has a Blinn / Fresnel / specular / measured lobe: the diffuse-only kernel alone
     int light_ns[16];
@@ -1360,8 +1361,12 @@ extern "C" int pt_render(pt_ctx *c, const pt_camera *cam, const pt_film_desc *fi
                 // queue, this level's shadow queue (its last reader, the any-hit trace of level - 2 or level - 1, is
                 // done: the wait above / stream order) and the next level's hit list
                 HIPCHK(c, pt_launch_list_hits(gs * 2, stream, qin, hit_list(level), qout.count, sh.count, hit_count(level + 1)));
+                // two kernels (all lobes / diffuse only) for the two hit lists only where the level can hold enough hits to pay for
+                // the second launch: a sparse level costs each launch its latency floor (shard 0 of 8, 8.4 M paths: 9.39 -> 9.20 ms
+                // with one kernel from level 1 on; the full 67 M-path render keeps two on levels 0-2: 64.0 against 64.1 ms)
+                const bool two_kernels = c->lobe_sets > 1 || (c->lobe_sets == 1 && ((long)nb >> (2 * level)) >= (1l << 24));
                 HIPCHK(c, pt_launch_shade(ig->kind, ig->shade_f32 != 0, gs, stream, c->sc, c->d_rc, base, level, qin,
-                                          hit_list(level), qout, sh, c->st, c->diffuse_back && c->lobe_sets, c->all_diffuse && c->lobe_sets));
+                                          hit_list(level), qout, sh, c->st, c->diffuse_back && two_kernels, c->all_diffuse && c->lobe_sets));
             }
             ShadowResolve rs = {sh.c, sh.stride, sh.slot, c->st.L, c->st.stride};
             hipStream_t any_stream = stream;

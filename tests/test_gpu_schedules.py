@@ -18,6 +18,8 @@ PLAIN = {'PT_TRACE_DYNAMIC': '0', 'PT_SHADE_DYNAMIC': '0', 'PT_TRACE_PACKET': '0
 VARIANTS = [
     {'PT_OVERLAP': '0'},                                                    # the defaults on one stream
     {'PT_OVERLAP': '0', 'PT_BATCH': '4096'},                                # many wavefront batches
+    {'PT_OVERLAP': '0', 'PT_SHADE_LOBESETS': '2'},                          # the diffuse-only kernel for the back hit list on every level (default: large levels only)
+    {'PT_OVERLAP': '1', 'PT_SHADE_LOBESETS': '2', 'PT_BATCH': '4096'},
     {'PT_OVERLAP': '0', 'PT_TRACE_PACKET': '3'},                            # level-0 shadow rays per wave everywhere
     {'PT_OVERLAP': '0', 'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1', 'PT_REFILL_MIN': '5'},   # pair walk, eager refill (half-size records)
     {'PT_OVERLAP': '0', 'PT_TRACE_PAIR': '3', 'PT_PAIR_REFILL': '1', 'PT_REFILL_MIN': '5', 'PT_PAIR_HALF': '0'},   # ... full-size records
