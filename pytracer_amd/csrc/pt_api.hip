@@ -35,6 +35,7 @@ struct pt_ctx {
     bool have_scene;
     DScene sc;
     void *d_nodes, *d_tris, *d_verts, *d_mat, *d_flip, *d_mats, *d_lights, *d_top, *d_tex, *d_tex_scratch, *d_uv, *d_brdf, *d_tri_cls, *d_frames;
+    void *d_box;             // the boxes of all nodes at 48-byte stride (DScene::node_box): trees that k_trace_meta(_s) can walk
     void *d_meta;            // packed (offset, n_prim | axis) words of all nodes (DScene::node_meta)
     void *d_pairs_h;         // GPairH records (the same at half size)
     int pair_half;           // PT_PAIR_HALF: k_trace_pair_refill reads the half-size records; unset (-1) = yes
@@ -349,7 +350,7 @@ extern "C" int pt_launch_log(pt_ctx *c, pt_launch_record *out, int32_t cap, int3
 
 static void free_scene(pt_ctx *c) {
     void **ps[] = {&c->d_nodes, &c->d_tris, &c->d_verts, &c->d_mat, &c->d_flip, &c->d_mats, &c->d_lights, &c->d_top,
-                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill, &c->d_tri_cls, &c->d_frames, &c->d_meta, &c->d_pairs_h};
+                   &c->d_tex, &c->d_tex_scratch, &c->d_uv, &c->d_brdf, &c->d_pairs, &c->d_spill, &c->d_tri_cls, &c->d_frames, &c->d_meta, &c->d_pairs_h, &c->d_box};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -736,6 +737,14 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     {
         const int levels = (std::max(depth, 1) + 3) & ~3;
         if (d->n_nodes > 0 && pt_trace_meta_lds(levels, d->n_nodes) <= (size_t)160 * 1024 - 1024) c->meta_stack = levels;
+        if (c->meta_stack > 0) {        // the boxes alone, 48 bytes apart: what k_trace_meta(_s) fetches per visit
+            std::vector<double> box(6 * (size_t)d->n_nodes);
+            for (int i = 0; i < d->n_nodes; i++) {
+                memcpy(&box[6 * (size_t)i], nodes[i].bmin, 3 * sizeof(double));
+                memcpy(&box[6 * (size_t)i + 3], nodes[i].bmax, 3 * sizeof(double));
+            }
+            HIPCHK(c, upload(&c->d_box, box.data(), box.size()));
+        }
         long k = ((long)160 * 1024 - 1024 - (long)levels * 4096) / (long)sizeof(TopNode);
         if (const char *e = getenv("PT_TOP_NODES")) k = std::min(k, atol(e));
         k = std::min<long>(k, d->n_nodes);
@@ -821,6 +830,7 @@ static int scene_upload_impl(pt_ctx *c, const pt_scene_desc *d) {
     DScene &s = c->sc;
     s.nodes = (const GNode *)c->d_nodes;
     s.node_meta = (const int2 *)c->d_meta;
+    s.node_box = (const double2 *)c->d_box;
     s.pairs = (const GPair *)c->d_pairs;
     s.pairs_h = (const GPairH *)c->d_pairs_h;
     s.top = n_top ? (const TopNode *)c->d_top : nullptr;

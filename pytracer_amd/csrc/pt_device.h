@@ -156,6 +156,7 @@ struct DScene {
     const TopNode *top;        // the first n_top nodes in breadth-first order, (k_tri_frames at upload)
     int32_t n_top;
     int32_t exact_slab;        // a node box with min > max (or NaN): only the reference's own comparison order is exact
+    const double2 *node_box;   // [n_nodes][3] the boxes alone at 48-byte stride (bmin.xy | bmin.z bmax.x | bmax.yz), or null
     const int2 *node_meta;     // [n_nodes] (offset, n_prim | axis << 16) of every node, packed: what k_trace_meta stages in LDS
     const GTri *tris;
     const double *tri_verts;   // [n_tris][9] p1,p2,p3 for shading geometry
