@@ -1321,11 +1321,14 @@ __device__ __forceinline__ double2 pk_load(const void *base, int i) {
     const pk_d2 v = ((pk_cd2)(unsigned long long)base)[i];
     return make_double2(v.x, v.y);
 }
+// waves per SIMD (head mesh, level-0 launches of the 1024^2 x 64 spp render, ms): closest hit 4 / 5 / 6 / 8 -> 5.48 / 5.69 /
+// 5.15 (79 VGPRs, 12 B of scratch) / 11.9 (64 VGPRs, 72 B); any hit 5 / 6 / 8 -> 6.94 / 6.95 / 6.39 (60 VGPRs, 36 B).  One
+// walk per wave is a serial chain (scalar load -> test -> ballot -> stack): more waves hide it until the spills bite.
 #ifndef PT_PACKET_WAVES
-#define PT_PACKET_WAVES 5
+#define PT_PACKET_WAVES(ANY) ((ANY) ? 8 : 6)
 #endif
 template <bool ANY>
-__global__ __launch_bounds__(PT_BLOCK, PT_PACKET_WAVES) void k_trace_packet(DScene sc, const double *__restrict__ rays, long stride,
+__global__ __launch_bounds__(PT_BLOCK, PT_PACKET_WAVES(ANY)) void k_trace_packet(DScene sc, const double *__restrict__ rays, long stride,
                                                            const int *__restrict__ seg_counts, long seg,
                                                            int *__restrict__ out_prim, double *__restrict__ out_t,
                                                            double *__restrict__ out_b1, double *__restrict__ out_b2,
