@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes of one bench.py command line: kernel trace + stats, HBM traffic (FETCH_SIZE / WRITE_SIZE in
-# separate --pmc passes), SQ cycle split, L2 hit/miss.  usage: scripts/prof.sh <tag> <bench.py args...>
+# separate --pmc passes), SQ cycle split, L2 hit/miss, vector L1 tag accesses against its read requests to L2.  usage: scripts/prof.sh <tag> <bench.py args...>
 # Results: gpurun_out/prof_<tag>/{stats,fetch,write,sq,tcc}/p_results.db  →  tools/prof_summary.py, tools/sq_summary.py
 set -o pipefail
 tag=$1; shift
@@ -21,4 +21,5 @@ run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
 run tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+run tcp --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 find $out -name '*.db' | head; du -sh $out

@@ -15,6 +15,7 @@ prof() {  # tag, bench args
     python3 tools/prof_summary.py ${R}_$t $d/stats/p_results.db $d/fetch/p_results.db $d/write/p_results.db $extra > /dev/null
     python3 tools/sq_summary.py ${R}_$t $d/sq/p_results.db > /dev/null
     python3 tools/tcc_summary.py ${R}_$t $d/tcc/p_results.db > /dev/null
+    python3 tools/tcp_summary.py ${R}_$t $d/tcp/p_results.db > /dev/null
     mkdir -p gpurun_out/profiles_out/json_$t
     cp $d/*.json gpurun_out/profiles_out/json_$t/
     rm -rf $d
