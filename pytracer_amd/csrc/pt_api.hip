@@ -945,7 +945,8 @@ static hipError_t launch_trace(pt_ctx *c, bool any, long n_bound, hipStream_t st
         *kid = refill ? PT_KERNEL_TRACE_PAIR_REFILL : PT_KERNEL_TRACE_PAIR;
         return pt_launch_trace_pair(any, c->pair_lds_levels, spill, (int)grid, stream, c->sc, rays, stride, seg_counts,
                                     seg, refill ? (n_val | PT_TRACE_REFILL | (half ? PT_TRACE_HALF : 0)) : n_val, out_prim, out_t, out_b1, out_b2, rs, counters,
-                                    c->refill_min, order);
+                                    c->refill_min ? c->refill_min : (half ? 24 : 0),   // half-size records: 24 waiting lanes (soup closest 55.3 -> 54.6 ms); else the kernel's 32
+                                    order);
     }
     // ... for launches that can hold enough rays to pay for its 1024-thread workgroups and their LDS staging: a launch
     // bounded by fewer than 2^20 rays runs the plain kernel (C1, 16 k camera rays: closest-hit 0.170 -> 0.125 ms,
